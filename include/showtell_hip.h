@@ -1,0 +1,110 @@
+/*
+ * showtell_hip.h -- C ABI of libshowtell_hip.so, the MI355X (gfx950) kernels of the
+ * show-tell captioning hot path.
+ *
+ * The reference (guptakhil/show-tell) has no FFI layer: its hot path is the Python
+ * nn.Module surface (cnn.py, rnn.py, Attention/rnn_attn.py, LSTM/rnn_lstm.py) whose
+ * arithmetic is delegated to torch / cuDNN / cuBLAS.  Each entry point below
+ * replaces one such delegated call site (cited as file:line of /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - every function returns 0 on success, non-zero on error;
+ *     st_last_error() returns a thread-local message;
+ *   - nothing is allocated, freed or synchronised inside a call (graph-capturable);
+ *     workspaces are caller-provided;
+ *   - dtype codes: ST_F32 = 0, ST_BF16 = 1.  bf16 tensors are raw uint16 bit patterns.
+ *   - activations are NHWC ("pixel-major"), weights are [Cout][KH][KW][Cin].
+ */
+#ifndef SHOWTELL_HIP_H
+#define SHOWTELL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_F32 0
+#define ST_BF16 1
+
+#define ST_CELL_GRU 0
+#define ST_CELL_LSTM 1
+
+const char* st_last_error(void);
+int st_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / dense projection on MFMA.
+ *   y[m][n] = sum_k x_gather[m][k] * w[n][k]        m = (b,ho,wo), k = (kh,kw,c)
+ * Replaces: torchvision conv2d inside cnn.py:46 / cnn_attn.py:46 (cuDNN conv),
+ * nn.Linear at cnn.py:49, rnn.py:33 and the GRU input projections inside rnn.py:32.
+ * A plain GEMM is the case KH=KW=1, Hin=Win=Ho=Wo=1, B=M, Cin=K.
+ * Epilogue (all optional, in this order):  v = acc + bias[n];  stats[n] += v, stats[N+n] += v*v
+ * (fp32 atomics, batch-norm statistics);  v = v*scale[n] + shift[n];  v += residual[m][n];
+ * v = max(v,0) if relu;  y = (accumulate ? y : 0) + v.
+ * Requirements: Cin, ldx, ldw multiples of 8 (bf16) / 4 (f32); ldy multiple of 4.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;        /* [B,Hin,Win,ldx] dtype                                    */
+  const void* w;        /* [N][ldw] dtype, K = KH*KW*Cin contiguous                 */
+  void* y;              /* [M][ldy] out_dtype, M = B*Ho*Wo                          */
+  const float* bias;    /* [N] or NULL                                              */
+  const float* scale;   /* [N] or NULL                                              */
+  const float* shift;   /* [N] or NULL                                              */
+  const void* residual; /* [M][ldy] out_dtype or NULL                               */
+  float* stats;         /* [2N] or NULL                                             */
+  int dtype, out_dtype;
+  int B, Hin, Win, Cin, Ho, Wo, N, KH, KW, stride, pad;
+  int ldx, ldw, ldy;
+  int relu, accumulate;
+} st_conv_desc;
+
+int st_conv(const st_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Batch-norm apply (+ residual)(+ ReLU), NHWC, fused elementwise pass.
+ * Replaces: nn.BatchNorm2d + ReLU + residual add inside torchvision's Bottleneck
+ * (cnn.py:46).  Train mode (main.py:125): stats = [sum | sumsq] from st_conv, count = B*H*W.
+ *   scale = gamma*rsqrt(var+eps), shift = beta - mean*scale   (biased var)
+ *   y = relu?( x*scale+shift + (res ? (res_stats ? res*rscale+rshift : res) : 0) )
+ * Eval mode: pass stats = NULL and running_mean/var.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; void* y; const void* res;      /* [rows][C] dtype                  */
+  const float* stats;  const float* gamma; const float* beta;
+  const float* running_mean; const float* running_var;      /* eval mode            */
+  const float* res_stats; const float* res_gamma; const float* res_beta;
+  const float* res_running_mean; const float* res_running_var;
+  int res_bn;          /* 1: residual goes through its own BN (downsample branch)   */
+  int dtype; long rows; int C; float count; float eps; int relu;
+} st_bn_act_desc;
+
+int st_bn_act(const st_bn_act_desc* d, void* stream);
+
+/* running_mean/var momentum update from [sum|sumsq] (unbiased var), nn.BatchNorm semantics */
+int st_bn_update_running(const float* stats, float* running_mean, float* running_var,
+                         int C, float count, float momentum, void* stream);
+
+/* NCHW fp32 images (utils.py:61-77 layout) -> NHWC dtype with channels zero-padded to Cpad */
+int st_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cpad, void* stream);
+/* NHWC dtype -> (B,C,H*W) fp32, the layout cnn_attn.py:49 returns */
+int st_nhwc_to_ncp_f32(const void* x, float* y, int dtype, int B, int HW, int C, void* stream);
+/* 3x3 stride-2 pad-1 max pool NHWC (torchvision resnet maxpool, cnn.py:46) */
+int st_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream);
+/* global average pool NHWC -> [B][C] (adaptive avgpool, cnn.py:34) */
+int st_global_avgpool(const void* x, void* y, int dtype, int out_dtype, int B, int HW, int C, void* stream);
+
+/* Generic helpers */
+int st_cast(const void* x, void* y, int from_dtype, int to_dtype, long n, void* stream);
+/* y[c][r] = x[r][c]; y has leading dimension ldy >= rows, pad columns zero-filled */
+int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx, int ldy, void* stream);
+/* conv weight repack: [Cout][Cin][KH][KW] fp32 (torch layout) -> [Cout][KH][KW][Cpad] dtype */
+int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""ctypes binding of libshowtell_hip.so (the C ABI declared in include/showtell_hip.h).
+
+There is no CPU fallback: if the HIP library is missing, every op raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libshowtell_hip.so")
+
+ST_F32, ST_BF16 = 0, 1
+ST_CELL_GRU, ST_CELL_LSTM = 0, 1
+
+c_p, c_i, c_f, c_l = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", c_p), ("w", c_p), ("y", c_p), ("bias", c_p), ("scale", c_p), ("shift", c_p),
+                ("residual", c_p), ("stats", c_p), ("dtype", c_i), ("out_dtype", c_i),
+                ("B", c_i), ("Hin", c_i), ("Win", c_i), ("Cin", c_i), ("Ho", c_i), ("Wo", c_i), ("N", c_i),
+                ("KH", c_i), ("KW", c_i), ("stride", c_i), ("pad", c_i),
+                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i)]
+
+
+class BnActDesc(C.Structure):
+    _fields_ = [("x", c_p), ("y", c_p), ("res", c_p), ("stats", c_p), ("gamma", c_p), ("beta", c_p),
+                ("running_mean", c_p), ("running_var", c_p), ("res_stats", c_p), ("res_gamma", c_p),
+                ("res_beta", c_p), ("res_running_mean", c_p), ("res_running_var", c_p), ("res_bn", c_i),
+                ("dtype", c_i), ("rows", c_l), ("C", c_i), ("count", c_f), ("eps", c_f), ("relu", c_i)]
+
+
+_SIGS = {
+    "st_version": ([], c_i),
+    "st_conv": ([C.POINTER(ConvDesc), c_p], c_i),
+    "st_bn_act": ([C.POINTER(BnActDesc), c_p], c_i),
+    "st_bn_update_running": ([c_p, c_p, c_p, c_i, c_f, c_f, c_p], c_i),
+    "st_nchw_to_nhwc": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_nhwc_to_ncp_f32": ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_maxpool3x3s2": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_global_avgpool": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_cast": ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
+    "st_transpose": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_pack_conv_weight": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+}
+
+_lib = None
+
+
+class ShowTellHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every entry point include/showtell_hip.h declares (kept in sync by tests/test_abi.py)."""
+    return sorted(list(_SIGS.keys()) + ["st_last_error"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ShowTellHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(LIB_PATH)
+        L.st_last_error.restype = C.c_char_p
+        L.st_last_error.argtypes = []
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ShowTellHipError(f"{what}: {lib().st_last_error().decode()}")

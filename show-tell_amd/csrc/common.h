@@ -1,0 +1,56 @@
+// Shared device/host helpers for libshowtell_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/showtell_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+void st_set_error(const char* fmt, ...);
+
+#define ST_CHECK(cond, ...)                                                   \
+  do {                                                                        \
+    if (!(cond)) { st_set_error(__VA_ARGS__); return 1; }                     \
+  } while (0)
+
+#define ST_LAUNCH_CHECK()                                                     \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) { st_set_error("%s:%d launch: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return 1; } \
+  } while (0)
+
+static inline size_t st_dtype_size(int dt) { return dt == ST_BF16 ? 2 : 4; }
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  bf16_t b = (bf16_t)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+  return *reinterpret_cast<uint16_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -1,0 +1,366 @@
+// HBM-bound elementwise / layout kernels of the encoder path (gfx950).
+// Every kernel moves 16 bytes per lane per access and grid-strides over a capped grid.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+inline int grid_for(long work, int threads) {
+  long b = (work + threads - 1) / threads;
+  return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
+}
+
+template <typename T> struct Vec;   // 16-byte vector of T
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const void* p, float* f) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(v[i] << 16); f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(void* p, const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(p) = v;
+  }
+};
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const void* p, float* f) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = v[i];
+  }
+  static __device__ __forceinline__ void store(void* p, const float* f) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// batch-norm apply (+ residual [+ its own BN]) (+ ReLU)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void bn_coeff(const float* stats, const float* gamma, const float* beta,
+                                         const float* rmean, const float* rvar, int C, int c,
+                                         float inv_count, float eps, float& sc, float& sh) {
+  float mean, var;
+  if (stats) {
+    mean = stats[c] * inv_count;
+    var = fmaxf(stats[C + c] * inv_count - mean * mean, 0.f);
+  } else {
+    mean = rmean[c]; var = rvar[c];
+  }
+  sc = gamma[c] * rsqrtf(var + eps);
+  sh = beta[c] - mean * sc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(st_bn_act_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float coef[];  // [sc | sh | rsc | rsh] x C
+  const int C = d.C;
+  const float inv = 1.0f / d.count;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sc, sh;
+    bn_coeff(d.stats, d.gamma, d.beta, d.running_mean, d.running_var, C, c, inv, d.eps, sc, sh);
+    coef[c] = sc; coef[C + c] = sh;
+    if (d.res_bn) {
+      bn_coeff(d.res_stats, d.res_gamma, d.res_beta, d.res_running_mean, d.res_running_var, C, c, inv, d.eps, sc, sh);
+      coef[2 * C + c] = sc; coef[3 * C + c] = sh;
+    }
+  }
+  __syncthreads();
+  constexpr int N = Vec<T>::N;
+  const long nchunk = d.rows * C / N;
+  const T* x = reinterpret_cast<const T*>(d.x);
+  const T* r = reinterpret_cast<const T*>(d.res);
+  T* y = reinterpret_cast<T*>(d.y);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * N;
+    const int c = (int)(e % C);
+    float v[N];
+    Vec<T>::load(x + e, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = v[k] * coef[c + k] + coef[C + c + k];
+    if (r) {
+      float rv[N];
+      Vec<T>::load(r + e, rv);
+      if (d.res_bn) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += rv[k] * coef[2 * C + c + k] + coef[3 * C + c + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += rv[k];
+      }
+    }
+    if (d.relu) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    Vec<T>::store(y + e, v);
+  }
+}
+
+__global__ void bn_update_running_kernel(const float* stats, float* rm, float* rv, int C, float count, float mom) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = stats[c] / count;
+  const float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);
+  const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+  rm[c] = (1.f - mom) * rm[c] + mom * mean;
+  rv[c] = (1.f - mom) * rv[c] + mom * unbiased;
+}
+
+// ---------------------------------------------------------------------------------------
+// layout
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y,
+                                                            int B, int C, int HW, int Cpad) {
+  const long npix = (long)B * HW;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const long b = p / HW, hw = p - b * HW;
+    for (int c0 = 0; c0 < Cpad; c0 += Vec<T>::N) {
+      float v[Vec<T>::N];
+#pragma unroll
+      for (int k = 0; k < Vec<T>::N; ++k) v[k] = (c0 + k < C) ? x[(b * C + c0 + k) * HW + hw] : 0.f;
+      Vec<T>::store(y + p * Cpad + c0, v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_ncp_kernel(const T* __restrict__ x, float* __restrict__ y,
+                                                           int B, int HW, int C) {
+  // one block per (b, 64-channel slab): stage [HW][64] through LDS, write [64][HW] rows
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [HW][65]
+  const int nslab = C / 64;
+  const int b = blockIdx.x / nslab, c0 = (blockIdx.x - b * nslab) * 64;
+  for (int i = threadIdx.x; i < HW * 64; i += blockDim.x) {
+    const int p = i >> 6, c = i & 63;
+    tile[p * 65 + c] = to_f32<T>(x[((long)b * HW + p) * C + c0 + c]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW * 64; i += blockDim.x) {
+    const int c = i / HW, p = i - c * HW;
+    y[((long)b * C + c0 + c) * HW + p] = tile[p * 65 + c];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       int B, int H, int W, int C, int Ho, int Wo) {
+  constexpr int N = Vec<T>::N;
+  const int cv = C / N;
+  const long total = (long)B * Ho * Wo * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * N;
+    long p = i / cv;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const long b = p / Ho;
+    float m[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) m[k] = -INFINITY;
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hi = ho * 2 - 1 + dh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wi = wo * 2 - 1 + dw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        float v[N];
+        Vec<T>::load(x + ((b * H + hi) * W + wi) * C + c, v);
+#pragma unroll
+        for (int k = 0; k < N; ++k) m[k] = fmaxf(m[k], v[k]);
+      }
+    }
+    Vec<T>::store(y + ((b * Ho + ho) * Wo + wo) * C + c, m);
+  }
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, TO* __restrict__ y, int B, int HW, int C) {
+  constexpr int N = Vec<T>::N;
+  const int cv = C / N;
+  const long total = (long)B * cv;
+  const float inv = 1.0f / HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / cv;
+    const int c = (int)(i - b * cv) * N;
+    float s[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) s[k] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      float v[N];
+      Vec<T>::load(x + (b * HW + p) * C + c, v);
+#pragma unroll
+      for (int k = 0; k < N; ++k) s[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) y[b * C + c + k] = from_f32<TO>(s[k] * inv);
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = from_f32<TO>(to_f32<TI>(x[i]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                         int rows, int cols, int ldx, int ldy) {
+  __shared__ T tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? x[(long)r * ldx + c] : from_f32<T>(0.f);
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < ldy) y[(long)c * ldy + r] = tile[tx][i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out,
+                                                                int Cout, int Cin, int KH, int KW, int Cpad) {
+  const long total = (long)Cout * KH * KW * Cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    long t = i / Cpad;
+    const int kw = (int)(t % KW); t /= KW;
+    const int kh = (int)(t % KH);
+    const long co = t / KH;
+    out[i] = from_f32<T>(c < Cin ? w[((co * Cin + c) * KH + kh) * KW + kw] : 0.f);
+  }
+}
+
+}  // namespace
+
+#define ST_DT_CHECK(dt, name) ST_CHECK((dt) == ST_F32 || (dt) == ST_BF16, name ": bad dtype %d", (dt))
+
+extern "C" int st_bn_act(const st_bn_act_desc* d, void* stream) {
+  ST_CHECK(d && d->x && d->y && d->gamma && d->beta, "st_bn_act: null pointer");
+  ST_DT_CHECK(d->dtype, "st_bn_act");
+  ST_CHECK(d->stats || (d->running_mean && d->running_var), "st_bn_act: need stats or running buffers");
+  const int n = d->dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(d->C % n == 0, "st_bn_act: C=%d must be a multiple of %d", d->C, n);
+  if (d->res_bn) {
+    ST_CHECK(d->res && d->res_gamma && d->res_beta && (d->res_stats || (d->res_running_mean && d->res_running_var)),
+             "st_bn_act: residual BN needs its parameters");
+  }
+  ST_CHECK(d->C <= 8192, "st_bn_act: C too large");
+  const long nchunk = d->rows * d->C / n;
+  const int grid = grid_for(nchunk, 256);
+  const size_t lds = (size_t)(d->res_bn ? 4 : 2) * d->C * sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == ST_BF16) hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, *d);
+  else hipLaunchKernelGGL(bn_act_kernel<float>, dim3(grid), dim3(256), lds, st, *d);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_bn_update_running(const float* stats, float* rm, float* rv, int C, float count, float momentum, void* stream) {
+  ST_CHECK(stats && rm && rv && C > 0, "st_bn_update_running: bad arguments");
+  hipLaunchKernelGGL(bn_update_running_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     stats, rm, rv, C, count, momentum);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cpad, void* stream) {
+  ST_CHECK(x && y, "st_nchw_to_nhwc: null pointer");
+  ST_DT_CHECK(dtype, "st_nchw_to_nhwc");
+  ST_CHECK(Cpad >= C && Cpad % (dtype == ST_BF16 ? 8 : 4) == 0, "st_nchw_to_nhwc: bad Cpad=%d", Cpad);
+  const int grid = grid_for((long)B * H * W, 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t*)y, B, C, H * W, Cpad);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)y, B, C, H * W, Cpad);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_nhwc_to_ncp_f32(const void* x, float* y, int dtype, int B, int HW, int C, void* stream) {
+  ST_CHECK(x && y, "st_nhwc_to_ncp_f32: null pointer");
+  ST_DT_CHECK(dtype, "st_nhwc_to_ncp_f32");
+  ST_CHECK(C % 64 == 0 && HW * 65 * 4 <= 64 * 1024, "st_nhwc_to_ncp_f32: needs C%%64==0 and HW<=252 (got C=%d HW=%d)", C, HW);
+  const int grid = B * (C / 64);
+  const size_t lds = (size_t)HW * 65 * sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(nhwc_to_ncp_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, (const bf16_t*)x, y, B, HW, C);
+  else hipLaunchKernelGGL(nhwc_to_ncp_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)x, y, B, HW, C);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream) {
+  ST_CHECK(x && y, "st_maxpool3x3s2: null pointer");
+  ST_DT_CHECK(dtype, "st_maxpool3x3s2");
+  const int n = dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(C % n == 0, "st_maxpool3x3s2: C=%d must be a multiple of %d", C, n);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int grid = grid_for((long)B * Ho * Wo * (C / n), 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
+  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_global_avgpool(const void* x, void* y, int dtype, int out_dtype, int B, int HW, int C, void* stream) {
+  ST_CHECK(x && y, "st_global_avgpool: null pointer");
+  ST_DT_CHECK(dtype, "st_global_avgpool");
+  ST_DT_CHECK(out_dtype, "st_global_avgpool");
+  const int n = dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(C % n == 0, "st_global_avgpool: C=%d must be a multiple of %d", C, n);
+  const int grid = grid_for((long)B * (C / n), 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16 && out_dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, HW, C);
+  else if (dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (float*)y, B, HW, C);
+  else if (out_dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)x, (bf16_t*)y, B, HW, C);
+  else hipLaunchKernelGGL((avgpool_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, HW, C);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_cast(const void* x, void* y, int from_dtype, int to_dtype, long n, void* stream) {
+  ST_CHECK(x && y, "st_cast: null pointer");
+  ST_DT_CHECK(from_dtype, "st_cast");
+  ST_DT_CHECK(to_dtype, "st_cast");
+  if (n <= 0) return 0;
+  const int grid = grid_for(n, 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (from_dtype == ST_F32 && to_dtype == ST_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)x, (bf16_t*)y, n);
+  else if (from_dtype == ST_BF16 && to_dtype == ST_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (float*)y, n);
+  else if (from_dtype == ST_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, n);
+  else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx, int ldy, void* stream) {
+  ST_CHECK(x && y, "st_transpose: null pointer");
+  ST_DT_CHECK(dtype, "st_transpose");
+  ST_CHECK(ldx >= cols && ldy >= rows, "st_transpose: leading dimensions too small");
+  const dim3 grid((cols + 63) / 64, (ldy + 63) / 64);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, cols, ldx, ldy);
+  else hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, rows, cols, ldx, ldy);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, void* stream) {
+  ST_CHECK(w && out, "st_pack_conv_weight: null pointer");
+  ST_DT_CHECK(dtype, "st_pack_conv_weight");
+  ST_CHECK(Cpad >= Cin, "st_pack_conv_weight: Cpad < Cin");
+  const long total = (long)Cout * KH * KW * Cpad;
+  const int grid = grid_for(total, 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin, KH, KW, Cpad);
+  else hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)out, Cout, Cin, KH, KW, Cpad);
+  ST_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,344 @@
+// Implicit-GEMM convolution / dense projection for gfx950 (MI355X) on MFMA.
+//
+//   y[m][n] = sum_k x_gather[m][k] * w[n][k]      m = (b,ho,wo)   k = (kh,kw,c)
+//
+// Replaces the cuDNN convolutions behind torchvision's ResNet (reference cnn.py:46,
+// cnn_attn.py:46) and the cuBLAS GEMMs behind nn.Linear / nn.GRU input projections
+// (cnn.py:49, rnn.py:32-33).  Not a translation of either: NHWC activations, [N][K]
+// weights, one kernel template for 1x1 / 3x3 / 7x7 / plain GEMM.
+//
+// Structure (CDNA4):
+//   * tile rows are 128 bytes of K (64 bf16 / 32 f32) = 8 chunks of 16 B; a row's chunk c
+//     is stored at chunk slot c ^ (row & 7)  -> ds_read_b128 of a 16x(K=32) MFMA operand
+//     is bank-conflict free (checked against the gfx950 ds_read_b128 lane groups).
+//   * global -> registers -> LDS staging (zero fill for padding / ragged edges), the
+//     next K-tile's global loads are issued before the MFMAs of the current one and
+//     written to the other LDS buffer afterwards: one barrier per K-step.
+//   * operands are swapped (weights = MFMA "A", pixels = MFMA "B") so every lane ends
+//     with 4 consecutive output channels of one pixel: 8-byte (bf16) / 16-byte (f32)
+//     stores and a cheap 16-lane reduction for the batch-norm statistics.
+//   * bf16: v_mfma_f32_16x16x32_bf16; f32: 4 x v_mfma_f32_16x16x4_f32 per 16-byte chunk
+//     (exact fp32 fma chain; k order inside a chunk is permuted identically for both
+//     operands, which leaves the sum unchanged up to association).
+//   * blockIdx is remapped so that blocks of one XCD walk neighbouring tiles
+//     (pixel tile major), sharing the activation rows in that XCD's L2.
+#include "common.h"
+
+namespace {
+
+struct IgemmArgs {
+  const void* x; const void* w; void* y;
+  const float* bias; const float* scale; const float* shift; const void* residual; float* stats;
+  int M, N, K;
+  int Hin, Win, Cin, Ho, Wo, KH, KW, stride, pad;
+  int ldx, ldw, ldy;
+  int relu, accumulate, out_f32;
+  int nbm, nbn;
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<float> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int BK = 8 * EPC;                // K elements per tile row (128 bytes)
+  constexpr int RPP = NT / 8;                // rows covered per loader pass
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
+  constexpr int TILE_BYTES = (BM + BN) * 128;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- XCD-aware tile assignment (bijective for any grid size) -------------------
+  const int nblk = a.nbm * a.nbn;
+  int lid;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int bm = lid / a.nbn, bn = lid - bm * a.nbn;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid - wm * WN;
+
+  // ---- loader state ----------------------------------------------------------------
+  const int ccol = tid & 7, lrow = tid >> 3;
+  int pixbase[PA], hw0[PA];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = bm * BM + lrow + i * RPP;
+    if (m < a.M) {
+      const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      pixbase[i] = b * a.Hin * a.Win;
+      const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+      hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
+    } else {
+      pixbase[i] = 0;
+      hw0[i] = (int)0x80008000;  // hi0 = wi0 = -32768: never in range
+    }
+  }
+  long wrow[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int n = bn * BN + lrow + i * RPP;
+    wrow[i] = n < a.N ? (long)n * a.ldw : -1;
+  }
+  // running (kh, kw, c) of this thread's chunk column
+  int kc = ccol * EPC, kh = 0, kw = 0;
+  while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+  int klin = ccol * EPC;
+
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
+
+  u32x4 ra[PA], rb[PB];
+  auto gload = [&]() {
+    const bool kok = kh < a.KH;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int hi = (hw0[i] >> 16) + kh, wi = (int)(short)(hw0[i] & 0xffff) + kw;
+      const bool ok = kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x4*>(X + ((long)(pixbase[i] + hi * a.Win + wi) * a.ldx + kc));
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kok && wrow[i] >= 0) v = *reinterpret_cast<const u32x4*>(W + (wrow[i] + klin));
+      rb[i] = v;
+    }
+    // advance to the next K tile
+    klin += BK;
+    kc += BK;
+    while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+  };
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int row = lrow + i * RPP;
+      *reinterpret_cast<u32x4*>(base + row * 128 + ((ccol ^ (row & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int row = lrow + i * RPP;
+      *reinterpret_cast<u32x4*>(base + (BM + row) * 128 + ((ccol ^ (row & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int nk = (a.K + BK - 1) / BK;
+
+  gload();
+  lstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) gload();
+    const char* base = smem + (kt & 1) * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int swz = ((ks * 4 + q4) ^ (r16 & 7)) << 4;
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const u32x4*>(base + (wm * (BM / WM) + i * 16 + r16) * 128 + swz);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const u32x4*>(base + (BM + wn * (BN / WN) + j * 16 + r16) * 128 + swz);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+    }
+    if (more) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------
+  // lane holds, for tile (i,j): pixel m = m0 + i*16 + r16, channels n = n0 + j*16 + 4*q4 + e
+  const int m0 = bm * BM + wm * (BM / WM), n0 = bn * BN + wn * (BN / WN);
+
+  if (a.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [2][BN][WM] after the final barrier
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s[4], ss[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = 0.f, v2 = 0.f;
+        const int n = n0 + j * 16 + 4 * q4 + e;
+        const float bz = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = m0 + i * 16 + r16;
+          const float t = (m < a.M) ? acc[i][j][e] + bz : 0.f;
+          v += t; v2 += t * t;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { v += __shfl_xor(v, o, 64); v2 += __shfl_xor(v2, o, 64); }
+        s[e] = v; ss[e] = v2;
+      }
+      if (r16 == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int nl = wn * (BN / WN) + j * 16 + 4 * q4 + e;
+          red[nl * WM + wm] = s[e];
+          red[(BN + nl) * WM + wm] = ss[e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * BN; t += NT) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[t * WM + w];
+      const int nl = t < BN ? t : t - BN;
+      const int n = bn * BN + nl;
+      if (n < a.N) atomicAdd(a.stats + (t < BN ? n : a.N + n), v);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + i * 16 + r16;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + j * 16 + 4 * q4;
+      if (n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+      const bool full = n + 3 < a.N;
+      const long off = (long)m * a.ldy + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (full || n + e < a.N) {
+          if (a.bias) v[e] += a.bias[n + e];
+          if (a.scale) v[e] = v[e] * a.scale[n + e] + a.shift[n + e];
+        }
+      }
+      if (a.out_f32) {
+        float* Y = reinterpret_cast<float*>(a.y) + off;
+        const float* R = a.residual ? reinterpret_cast<const float*>(a.residual) + off : nullptr;
+        if (full) {
+          if (R) { const f32x4 r = *reinterpret_cast<const f32x4*>(R); for (int e = 0; e < 4; ++e) v[e] += r[e]; }
+          if (a.relu) for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          if (a.accumulate) { const f32x4 o = *reinterpret_cast<const f32x4*>(Y); for (int e = 0; e < 4; ++e) v[e] += o[e]; }
+          *reinterpret_cast<f32x4*>(Y) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          for (int e = 0; e < 4 && n + e < a.N; ++e) {
+            float t = v[e];
+            if (R) t += R[e];
+            if (a.relu) t = fmaxf(t, 0.f);
+            if (a.accumulate) t += Y[e];
+            Y[e] = t;
+          }
+        }
+      } else {
+        uint16_t* Y = reinterpret_cast<uint16_t*>(a.y) + off;
+        const uint16_t* R = a.residual ? reinterpret_cast<const uint16_t*>(a.residual) + off : nullptr;
+        if (full) {
+          if (R) {
+            const u32x2 r = *reinterpret_cast<const u32x2*>(R);
+            v[0] += __uint_as_float(r[0] << 16); v[1] += __uint_as_float(r[0] & 0xffff0000u);
+            v[2] += __uint_as_float(r[1] << 16); v[3] += __uint_as_float(r[1] & 0xffff0000u);
+          }
+          if (a.relu) for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          if (a.accumulate) {
+            const u32x2 o = *reinterpret_cast<const u32x2*>(Y);
+            v[0] += __uint_as_float(o[0] << 16); v[1] += __uint_as_float(o[0] & 0xffff0000u);
+            v[2] += __uint_as_float(o[1] << 16); v[3] += __uint_as_float(o[1] & 0xffff0000u);
+          }
+          *reinterpret_cast<u32x2*>(Y) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        } else {
+          for (int e = 0; e < 4 && n + e < a.N; ++e) {
+            float t = v[e];
+            if (R) t += bf16_bits_to_f32(R[e]);
+            if (a.relu) t = fmaxf(t, 0.f);
+            if (a.accumulate) t += bf16_bits_to_f32(Y[e]);
+            Y[e] = f32_to_bf16_bits(t);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch(IgemmArgs& a, hipStream_t st) {
+  a.nbm = (a.M + BM - 1) / BM;
+  a.nbn = (a.N + BN - 1) / BN;
+  const int lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+int dispatch(IgemmArgs& a, hipStream_t st) {
+  // Tile choice: fill >= ~1.5 waves of the 256 CUs where the problem allows it.
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (a.N <= 64) return launch<T, 128, 64, 4, 1>(a, st);
+  if (t128 >= 384) return launch<T, 128, 128, 2, 2>(a, st);
+  const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+  if (t64 >= 256 || a.M <= 64) return launch<T, 64, 128, 1, 4>(a, st);
+  return launch<T, 128, 128, 2, 2>(a, st);
+}
+
+}  // namespace
+
+extern "C" int st_conv(const st_conv_desc* d, void* stream) {
+  ST_CHECK(d && d->x && d->w && d->y, "st_conv: null pointer");
+  ST_CHECK(d->dtype == ST_F32 || d->dtype == ST_BF16, "st_conv: bad dtype %d", d->dtype);
+  const int epc = d->dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(d->Cin > 0 && d->Cin % epc == 0, "st_conv: Cin=%d must be a multiple of %d", d->Cin, epc);
+  ST_CHECK(d->ldx % epc == 0 && d->ldw % epc == 0, "st_conv: ldx=%d/ldw=%d must be multiples of %d", d->ldx, d->ldw, epc);
+  ST_CHECK(d->ldx >= d->Cin && d->ldw >= d->KH * d->KW * d->Cin, "st_conv: leading dimensions too small");
+  ST_CHECK(d->ldy % 4 == 0 && d->ldy >= d->N, "st_conv: ldy=%d must be a multiple of 4 and >= N=%d", d->ldy, d->N);
+  ST_CHECK(d->B > 0 && d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0, "st_conv: bad geometry");
+  ST_CHECK(d->Hin < 32768 && d->Win < 32768, "st_conv: spatial size too large");
+  ST_CHECK((long)d->B * d->Hin * d->Win * d->ldx < (1L << 40), "st_conv: input too large");
+  ST_CHECK((d->scale == nullptr) == (d->shift == nullptr), "st_conv: scale and shift must be given together");
+  IgemmArgs a;
+  a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.scale = d->scale; a.shift = d->shift;
+  a.residual = d->residual; a.stats = d->stats;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->N; a.K = d->KH * d->KW * d->Cin;
+  a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy;
+  a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == ST_F32;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return d->dtype == ST_BF16 ? dispatch<bf16_t>(a, st) : dispatch<float>(a, st);
+}

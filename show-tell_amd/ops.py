@@ -1,0 +1,163 @@
+"""Tensor-level wrappers over the C ABI (torch supplies device memory and streams only).
+
+Every function checks shapes/dtypes on the host before a kernel is launched and
+raises ``ShowTellHipError`` on failure.  All tensors must live on a HIP device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ST_BF16, ST_F32, BnActDesc, ConvDesc, check, lib
+
+_DT = {torch.float32: ST_F32, torch.bfloat16: ST_BF16}
+
+
+def dt_code(t):
+    if t.dtype not in _DT:
+        raise _lib.ShowTellHipError(f"unsupported dtype {t.dtype}")
+    return _DT[t.dtype]
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.ShowTellHipError("tensor is not on the GPU (the HIP path has no CPU fallback)")
+        if t is not None and not t.is_contiguous():
+            raise _lib.ShowTellHipError("tensor must be contiguous")
+
+
+def conv_nhwc(x, w, KH, KW, stride, pad, out_dtype=None, bias=None, scale=None, shift=None,
+              residual=None, stats=None, relu=False, out=None, accumulate=False):
+    """x: (B,Hin,Win,Cin) NHWC; w: (N, KH*KW*Cin) K-contiguous.  Returns (B,Ho,Wo,N)."""
+    _dev(x, w, bias, scale, shift, residual, stats, out)
+    B, Hin, Win, Cin = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == KH * KW * Cin, (w.shape, KH, KW, Cin)
+    Ho = (Hin + 2 * pad - KH) // stride + 1
+    Wo = (Win + 2 * pad - KW) // stride + 1
+    out_dtype = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty(B, Ho, Wo, N, device=x.device, dtype=out_dtype)
+    assert out.shape == (B, Ho, Wo, N) and out.dtype == out_dtype
+    d = ConvDesc(_p(x), _p(w), _p(out), _p(bias), _p(scale), _p(shift), _p(residual), _p(stats),
+                 dt_code(x), _DT[out_dtype], B, Hin, Win, Cin, Ho, Wo, N, KH, KW, stride, pad,
+                 Cin, w.shape[1], N, int(relu), int(accumulate))
+    check(lib().st_conv(C.byref(d), _stream()), "st_conv")
+    return out
+
+
+def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=None, relu=False,
+            lda=None, ldw=None, K=None):
+    """y[M,N] = a[M,K] @ w[N,K]^T (+bias).  a, w may carry padded leading dimensions."""
+    _dev(a, w, bias, out, stats)
+    M = a.shape[0]
+    N = w.shape[0]
+    lda = lda or a.stride(0)
+    ldw = ldw or w.stride(0)
+    K = K or a.shape[1]
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype)
+    ldy = out.stride(0)
+    d = ConvDesc(_p(a), _p(w), _p(out), _p(bias), None, None, None, _p(stats),
+                 dt_code(a), _DT[out.dtype], M, 1, 1, K, 1, 1, N, 1, 1, 1, 0,
+                 lda, ldw, ldy, int(relu), int(accumulate))
+    check(lib().st_conv(C.byref(d), _stream()), "st_conv(gemm)")
+    return out
+
+
+def bn_act(x, gamma, beta, stats=None, running=None, count=1.0, eps=1e-5, relu=True, res=None,
+           res_bn=None, out=None):
+    """x: (..., C) channels-last.  res_bn = dict(gamma, beta, stats | running=(mean,var)) or None."""
+    _dev(x, gamma, beta, stats, res, out)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    if out is None:
+        out = torch.empty_like(x)
+    rm, rv = running if running is not None else (None, None)
+    rb = res_bn or {}
+    rrm, rrv = rb.get("running", (None, None))
+    d = BnActDesc(_p(x), _p(out), _p(res), _p(stats), _p(gamma), _p(beta), _p(rm), _p(rv),
+                  _p(rb.get("stats")), _p(rb.get("gamma")), _p(rb.get("beta")), _p(rrm), _p(rrv),
+                  int(res_bn is not None), dt_code(x), rows, Cc, float(count), float(eps), int(relu))
+    check(lib().st_bn_act(C.byref(d), _stream()), "st_bn_act")
+    return out
+
+
+def bn_update_running(stats, running_mean, running_var, count, momentum):
+    _dev(stats, running_mean, running_var)
+    check(lib().st_bn_update_running(_p(stats), _p(running_mean), _p(running_var), running_mean.numel(),
+                                     float(count), float(momentum), _stream()), "st_bn_update_running")
+
+
+def nchw_to_nhwc(x, dtype, cpad):
+    _dev(x)
+    assert x.dtype == torch.float32
+    B, Cc, H, W = x.shape
+    y = torch.empty(B, H, W, cpad, device=x.device, dtype=dtype)
+    check(lib().st_nchw_to_nhwc(_p(x), _p(y), _DT[dtype], B, Cc, H, W, cpad, _stream()), "st_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_ncp_f32(x):
+    _dev(x)
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, Cc, H * W, device=x.device, dtype=torch.float32)
+    check(lib().st_nhwc_to_ncp_f32(_p(x), _p(y), dt_code(x), B, H * W, Cc, _stream()), "st_nhwc_to_ncp_f32")
+    return y
+
+
+def maxpool3x3s2(x):
+    _dev(x)
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
+    check(lib().st_maxpool3x3s2(_p(x), _p(y), dt_code(x), B, H, W, Cc, _stream()), "st_maxpool3x3s2")
+    return y
+
+
+def global_avgpool(x, out_dtype=None):
+    _dev(x)
+    B, H, W, Cc = x.shape
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty(B, Cc, device=x.device, dtype=out_dtype)
+    check(lib().st_global_avgpool(_p(x), _p(y), dt_code(x), _DT[out_dtype], B, H * W, Cc, _stream()), "st_global_avgpool")
+    return y
+
+
+def cast(x, dtype, out=None):
+    _dev(x, out)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(lib().st_cast(_p(x), _p(out), dt_code(x), _DT[dtype], x.numel(), _stream()), "st_cast")
+    return out
+
+
+def transpose(x, ldy=None, out=None):
+    """x: (rows, cols) -> (cols, ldy) with ldy >= rows, zero padded."""
+    _dev(x, out)
+    rows, cols = x.shape
+    ldy = ldy or rows
+    if out is None:
+        out = torch.empty(cols, ldy, device=x.device, dtype=x.dtype)
+    check(lib().st_transpose(_p(x), _p(out), dt_code(x), rows, cols, x.stride(0), ldy, _stream()), "st_transpose")
+    return out
+
+
+def pack_conv_weight(w, dtype, cpad=None):
+    """(Cout,Cin,KH,KW) fp32 torch layout -> (Cout, KH*KW*Cpad) K-contiguous."""
+    _dev(w)
+    Cout, Cin, KH, KW = w.shape
+    cpad = cpad or Cin
+    out = torch.empty(Cout, KH * KW * cpad, device=w.device, dtype=dtype)
+    check(lib().st_pack_conv_weight(_p(w), _p(out), _DT[dtype], Cout, Cin, KH, KW, cpad, _stream()), "st_pack_conv_weight")
+    return out
