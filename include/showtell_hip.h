@@ -104,6 +104,36 @@ int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx,
 /* conv weight repack: [Cout][Cin][KH][KW] fp32 (torch layout) -> [Cout][KH][KW][Cpad] dtype */
 int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * ResNet-{18,34,50,101,152} backbone forward, one call (torchvision children()[:-1] /
+ * [:-2]; reference cnn.py:23-34,46 and cnn_attn.py:23-34,46-49).
+ * Layers are indexed in forward order: stem conv, then per block conv1, conv2, [conv3],
+ * [downsample]; st_resnet_conv_info gives geometry and the element offsets of layer i in
+ * the packed weight buffer ([Cout][KH][KW][Cin_padded], dtype) and in the concatenated
+ * BatchNorm arrays (gamma, beta, running_mean, running_var: fp32, one entry per channel).
+ * st_resnet_create returns 2 with the reference's ValueError text (cnn.py:33) for an
+ * unknown version.  Outputs (each optional): feat_nhwc_out (B,h,w,F) dtype;
+ * pooled_out (B,F) pooled_dtype (cnn.py:48); ncp_out (B,F,h*w) fp32 (cnn_attn.py:49).
+ * train != 0: batch statistics + running-buffer update (main.py:125); else eval mode.
+ * ---------------------------------------------------------------------------------- */
+typedef struct st_resnet st_resnet;
+int st_resnet_create(int version, int dtype, st_resnet** out);
+void st_resnet_destroy(st_resnet* r);
+int st_resnet_num_convs(const st_resnet* r);
+int st_resnet_feat_dim(const st_resnet* r);
+size_t st_resnet_weight_elems(const st_resnet* r);
+size_t st_resnet_bn_channels(const st_resnet* r);
+int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cout, int* k, int* stride, int* pad,
+                        int* cin_padded, size_t* weight_offset, size_t* bn_offset);
+size_t st_resnet_workspace_bytes(const st_resnet* r, int B, int H, int W);
+int st_resnet_forward(const st_resnet* r, const float* images_nchw, int B, int H, int W,
+                      const void* weights, const float* bn_gamma, const float* bn_beta,
+                      float* bn_running_mean, float* bn_running_var,
+                      int train, float momentum, float eps,
+                      void* workspace, size_t workspace_bytes,
+                      void* feat_nhwc_out, void* pooled_out, int pooled_dtype, float* ncp_out,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

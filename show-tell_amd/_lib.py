@@ -41,6 +41,16 @@ _SIGS = {
     "st_cast": ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
     "st_transpose": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_pack_conv_weight": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_resnet_create": ([c_i, c_i, C.POINTER(c_p)], c_i),
+    "st_resnet_destroy": ([c_p], None),
+    "st_resnet_num_convs": ([c_p], c_i),
+    "st_resnet_feat_dim": ([c_p], c_i),
+    "st_resnet_weight_elems": ([c_p], C.c_size_t),
+    "st_resnet_bn_channels": ([c_p], C.c_size_t),
+    "st_resnet_conv_info": ([c_p, c_i] + [C.POINTER(c_i)] * 6 + [C.POINTER(C.c_size_t)] * 2, c_i),
+    "st_resnet_workspace_bytes": ([c_p, c_i, c_i, c_i], C.c_size_t),
+    "st_resnet_forward": ([c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, C.c_size_t,
+                           c_p, c_p, c_i, c_p, c_p], c_i),
 }
 
 _lib = None

@@ -1,0 +1,296 @@
+// ResNet-{18,34,50,101,152} encoder forward as one C-ABI call (gfx950).
+//
+// Replaces `self.model(x)` of the reference encoder (cnn.py:46 / cnn_attn.py:46), i.e.
+// torchvision's resnet children()[:-1] / [:-2], and the reshape that follows it
+// (cnn.py:48 flatten of the pooled map, cnn_attn.py:49 view(B,2048,49)).
+//
+// The whole layer sequence is issued from C++ on one stream (no Python per layer, nothing
+// allocated or synchronised -> capturable in a hipGraph).  Activations are NHWC in `dtype`.
+//   train != 0 : every BatchNorm2d uses batch statistics (main.py:125 calls cnn.train()):
+//                conv epilogue accumulates per-channel sum / sum-of-squares, a fused
+//                elementwise pass normalises (+residual)(+ReLU) in place, one kernel updates
+//                all running buffers at the end.
+//   train == 0 : BN is folded to per-channel scale/shift once per call and applied in the
+//                conv epilogue together with the residual add and the ReLU.
+#include "common.h"
+#include <vector>
+#include <new>
+#include <string.h>
+
+struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; };
+struct BlockL { int c1, c2, c3, ds; int stride; };  // indices into convs (c3 = -1 for basic blocks, ds = -1 if none)
+
+struct st_resnet {
+  int version, dtype, bottleneck, cpad0;
+  std::vector<ConvL> convs;
+  std::vector<BlockL> blocks;
+  size_t wtotal = 0, bntotal = 0;
+  int feat_dim = 0;
+};
+
+namespace {
+
+struct BnTable { int n; int end[160]; float count[160]; };
+
+__global__ void bn_update_all_kernel(const float* __restrict__ stats, float* __restrict__ rm, float* __restrict__ rv,
+                                     int total, float mom, BnTable t) {
+  // stats holds, per layer l with channels [start_l, end_l): [sum(C_l) | sumsq(C_l)] at offset 2*start_l
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= total) return;
+  int l = 0;
+  while (l < t.n - 1 && c >= t.end[l]) ++l;
+  const int start = l == 0 ? 0 : t.end[l - 1];
+  const int C = t.end[l] - start;
+  const float cnt = t.count[l];
+  const float mean = stats[2 * start + (c - start)] / cnt;
+  const float var = fmaxf(stats[2 * start + C + (c - start)] / cnt - mean * mean, 0.f);
+  const float unb = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+  rm[c] = (1.f - mom) * rm[c] + mom * mean;
+  rv[c] = (1.f - mom) * rv[c] + mom * unb;
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv,
+                               float* __restrict__ scale, float* __restrict__ shift, int total, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= total) return;
+  const float sc = gamma[c] * rsqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
+
+}  // namespace
+
+extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
+  ST_CHECK(out, "st_resnet_create: null out");
+  ST_CHECK(dtype == ST_F32 || dtype == ST_BF16, "st_resnet_create: bad dtype %d", dtype);
+  int nb[4];
+  int bott;
+  switch (version) {
+    case 18: nb[0] = 2; nb[1] = 2; nb[2] = 2; nb[3] = 2; bott = 0; break;
+    case 34: nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; bott = 0; break;
+    case 50: nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; bott = 1; break;
+    case 101: nb[0] = 3; nb[1] = 4; nb[2] = 23; nb[3] = 3; bott = 1; break;
+    case 152: nb[0] = 3; nb[1] = 8; nb[2] = 36; nb[3] = 3; bott = 1; break;
+    default:
+      // same message as the reference (cnn.py:33)
+      st_set_error("Please specify a valid ResNet version. %d doesn't exist.", version);
+      return 2;
+  }
+  st_resnet* r = new (std::nothrow) st_resnet();
+  ST_CHECK(r, "st_resnet_create: out of memory");
+  r->version = version; r->dtype = dtype; r->bottleneck = bott;
+  const int epc = dtype == ST_BF16 ? 8 : 4;
+  r->cpad0 = epc;  // 3 input channels zero-padded to one 16-byte chunk
+  auto add = [&](int cin, int cout, int k, int s, int p) {
+    ConvL c{cin, cout, k, s, p, r->wtotal, r->bntotal};
+    const int cin_p = (cin == 3) ? r->cpad0 : cin;
+    r->wtotal += (size_t)cout * k * k * cin_p;
+    r->bntotal += cout;
+    r->convs.push_back(c);
+    return (int)r->convs.size() - 1;
+  };
+  add(3, 64, 7, 2, 3);
+  int inpl = 64;
+  const int planes[4] = {64, 128, 256, 512};
+  const int exp = bott ? 4 : 1;
+  for (int li = 0; li < 4; ++li)
+    for (int bi = 0; bi < nb[li]; ++bi) {
+      const int s = bi == 0 ? (li == 0 ? 1 : 2) : 1;
+      BlockL b; b.stride = s; b.c3 = -1; b.ds = -1;
+      if (bott) {
+        b.c1 = add(inpl, planes[li], 1, 1, 0);
+        b.c2 = add(planes[li], planes[li], 3, s, 1);
+        b.c3 = add(planes[li], planes[li] * 4, 1, 1, 0);
+      } else {
+        b.c1 = add(inpl, planes[li], 3, s, 1);
+        b.c2 = add(planes[li], planes[li], 3, 1, 1);
+      }
+      if (bi == 0 && (s != 1 || inpl != planes[li] * exp)) b.ds = add(inpl, planes[li] * exp, 1, s, 0);
+      inpl = planes[li] * exp;
+      r->blocks.push_back(b);
+    }
+  r->feat_dim = inpl;
+  ST_CHECK(r->convs.size() <= 160, "st_resnet_create: too many layers");
+  *out = r;
+  return 0;
+}
+
+extern "C" void st_resnet_destroy(st_resnet* r) { delete r; }
+extern "C" int st_resnet_num_convs(const st_resnet* r) { return r ? (int)r->convs.size() : -1; }
+extern "C" int st_resnet_feat_dim(const st_resnet* r) { return r ? r->feat_dim : -1; }
+extern "C" size_t st_resnet_weight_elems(const st_resnet* r) { return r ? r->wtotal : 0; }
+extern "C" size_t st_resnet_bn_channels(const st_resnet* r) { return r ? r->bntotal : 0; }
+
+extern "C" int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cout, int* k, int* stride, int* pad,
+                                   int* cin_padded, size_t* weight_offset, size_t* bn_offset) {
+  ST_CHECK(r && i >= 0 && i < (int)r->convs.size(), "st_resnet_conv_info: bad index %d", i);
+  const ConvL& c = r->convs[i];
+  if (cin) *cin = c.cin;
+  if (cout) *cout = c.cout;
+  if (k) *k = c.k;
+  if (stride) *stride = c.stride;
+  if (pad) *pad = c.pad;
+  if (cin_padded) *cin_padded = c.cin == 3 ? r->cpad0 : c.cin;
+  if (weight_offset) *weight_offset = c.woff;
+  if (bn_offset) *bn_offset = c.bnoff;
+  return 0;
+}
+
+namespace {
+struct Plan {
+  size_t in_bytes, stem_bytes, wide_bytes, narrow_bytes, stats_bytes, fold_bytes, total;
+};
+Plan make_plan(const st_resnet* r, int B, int H, int W) {
+  const size_t es = st_dtype_size(r->dtype);
+  Plan p;
+  p.in_bytes = align256((size_t)B * H * W * r->cpad0 * es);
+  const int h1 = conv_out(H, 7, 2, 3), w1 = conv_out(W, 7, 2, 3);
+  p.stem_bytes = align256((size_t)B * h1 * w1 * 64 * es);
+  const int h2 = conv_out(h1, 3, 2, 1), w2 = conv_out(w1, 3, 2, 1);
+  // widest block tensors live at layer1 resolution
+  const size_t wide_c = r->bottleneck ? 256 : 64;
+  p.wide_bytes = align256((size_t)B * h2 * w2 * wide_c * es);
+  p.narrow_bytes = align256((size_t)B * h2 * w2 * 128 * es);  // >= any conv1/conv2 output (layer2 conv1 at layer1 res: 128 ch)
+  p.stats_bytes = align256(2 * r->bntotal * sizeof(float));
+  p.fold_bytes = align256(2 * r->bntotal * sizeof(float));
+  p.total = p.in_bytes + p.stem_bytes + 3 * p.wide_bytes + 2 * p.narrow_bytes + p.stats_bytes + p.fold_bytes;
+  return p;
+}
+}  // namespace
+
+extern "C" size_t st_resnet_workspace_bytes(const st_resnet* r, int B, int H, int W) {
+  if (!r || B <= 0 || H < 32 || W < 32) return 0;
+  return make_plan(r, B, H, W).total;
+}
+
+extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, int B, int H, int W,
+                                 const void* weights, const float* bn_gamma, const float* bn_beta,
+                                 float* bn_running_mean, float* bn_running_var,
+                                 int train, float momentum, float eps,
+                                 void* workspace, size_t workspace_bytes,
+                                 void* feat_nhwc_out, void* pooled_out, int pooled_dtype, float* ncp_out,
+                                 void* stream) {
+  ST_CHECK(r && images_nchw && weights && bn_gamma && bn_beta && bn_running_mean && bn_running_var && workspace,
+           "st_resnet_forward: null pointer");
+  ST_CHECK(B > 0 && H >= 32 && W >= 32, "st_resnet_forward: bad input size %dx%dx%d", B, H, W);
+  const Plan p = make_plan(r, B, H, W);
+  ST_CHECK(workspace_bytes >= p.total, "st_resnet_forward: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int dt = r->dtype;
+  const size_t es = st_dtype_size(dt);
+  char* ws = reinterpret_cast<char*>(workspace);
+  char* in8 = ws; ws += p.in_bytes;
+  char* stem = ws; ws += p.stem_bytes;
+  char* wide[3] = {ws, ws + p.wide_bytes, ws + 2 * p.wide_bytes}; ws += 3 * p.wide_bytes;
+  char* narrow[2] = {ws, ws + p.narrow_bytes}; ws += 2 * p.narrow_bytes;
+  float* stats = reinterpret_cast<float*>(ws); ws += p.stats_bytes;
+  float* fold = reinterpret_cast<float*>(ws);
+  const int total = (int)r->bntotal;
+  float* fscale = fold; float* fshift = fold + total;
+
+  if (train) {
+    if (hipMemsetAsync(stats, 0, 2 * r->bntotal * sizeof(float), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
+  } else {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, bn_gamma, bn_beta, bn_running_mean,
+                       bn_running_var, fscale, fshift, total, eps);
+    ST_LAUNCH_CHECK();
+  }
+  if (st_nchw_to_nhwc(images_nchw, in8, dt, B, 3, H, W, r->cpad0, stream)) return 1;
+
+  BnTable tab; tab.n = (int)r->convs.size();
+  for (int i = 0; i < tab.n; ++i) { tab.end[i] = (int)(r->convs[i].bnoff + r->convs[i].cout); tab.count[i] = 1.f; }
+
+  // conv: train -> raw output + statistics; eval -> folded BN (+residual)(+ReLU) in the epilogue
+  auto conv = [&](int ci, const void* x, int hin, int win, void* y, const void* eval_res, int eval_relu,
+                  int* ho, int* wo) -> int {
+    const ConvL& c = r->convs[ci];
+    st_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    const int cin_p = c.cin == 3 ? r->cpad0 : c.cin;
+    d.x = x; d.w = reinterpret_cast<const char*>(weights) + c.woff * es; d.y = y;
+    d.dtype = dt; d.out_dtype = dt;
+    d.B = B; d.Hin = hin; d.Win = win; d.Cin = cin_p;
+    d.Ho = conv_out(hin, c.k, c.stride, c.pad); d.Wo = conv_out(win, c.k, c.stride, c.pad);
+    d.N = c.cout; d.KH = c.k; d.KW = c.k; d.stride = c.stride; d.pad = c.pad;
+    d.ldx = cin_p; d.ldw = c.k * c.k * cin_p; d.ldy = c.cout;
+    if (train) {
+      d.stats = stats + 2 * c.bnoff;
+    } else {
+      d.scale = fscale + c.bnoff; d.shift = fshift + c.bnoff; d.residual = eval_res; d.relu = eval_relu;
+    }
+    *ho = d.Ho; *wo = d.Wo;
+    tab.count[ci] = (float)((long)B * d.Ho * d.Wo);
+    return st_conv(&d, stream);
+  };
+  // train-mode normalise (+residual [+its BN]) (+ReLU), in place
+  auto bnact = [&](int ci, void* x, long rows, int relu, const void* res, int res_ci) -> int {
+    const ConvL& c = r->convs[ci];
+    st_bn_act_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.y = x; d.res = res;
+    d.stats = stats + 2 * c.bnoff; d.gamma = bn_gamma + c.bnoff; d.beta = bn_beta + c.bnoff;
+    if (res_ci >= 0) {
+      const ConvL& rc = r->convs[res_ci];
+      d.res_bn = 1; d.res_stats = stats + 2 * rc.bnoff; d.res_gamma = bn_gamma + rc.bnoff; d.res_beta = bn_beta + rc.bnoff;
+    }
+    d.dtype = dt; d.rows = rows; d.C = c.cout; d.count = (float)rows; d.eps = eps; d.relu = relu;
+    return st_bn_act(&d, stream);
+  };
+
+  int h, w;
+  if (conv(0, in8, H, W, stem, nullptr, 1, &h, &w)) return 1;
+  if (train && bnact(0, stem, (long)B * h * w, 1, nullptr, -1)) return 1;
+  if (st_maxpool3x3s2(stem, wide[0], dt, B, h, w, 64, stream)) return 1;
+  h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
+  int cur = 0;  // wide[cur] holds the block input
+
+  for (const BlockL& b : r->blocks) {
+    const int oth = (cur + 1) % 3, dsb = (cur + 2) % 3;
+    int h1, w1, h2, w2, h3, w3, hd, wd;
+    const void* xin = wide[cur];
+    if (r->bottleneck) {
+      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
+      if (train && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
+      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2)) return 1;
+      if (train && bnact(b.c2, narrow[1], (long)B * h2 * w2, 1, nullptr, -1)) return 1;
+      const void* res = xin;
+      if (b.ds >= 0) {
+        if (conv(b.ds, xin, h, w, wide[dsb], nullptr, 0, &hd, &wd)) return 1;
+        res = wide[dsb];
+      }
+      if (conv(b.c3, narrow[1], h2, w2, wide[oth], res, 1, &h3, &w3)) return 1;
+      if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
+    } else {
+      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
+      if (train && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
+      const void* res = xin;
+      if (b.ds >= 0) {
+        if (conv(b.ds, xin, h, w, wide[dsb], nullptr, 0, &hd, &wd)) return 1;
+        res = wide[dsb];
+      }
+      if (conv(b.c2, narrow[0], h1, w1, wide[oth], res, 1, &h3, &w3)) return 1;
+      if (train && bnact(b.c2, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
+    }
+    h = h3; w = w3; cur = oth;
+  }
+
+  const size_t feat_bytes = (size_t)B * h * w * r->feat_dim * es;
+  if (feat_nhwc_out) {
+    if (hipMemcpyAsync(feat_nhwc_out, wide[cur], feat_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      st_set_error("st_resnet_forward: copy failed"); return 1;
+    }
+  }
+  if (pooled_out && st_global_avgpool(wide[cur], pooled_out, dt, pooled_dtype, B, h * w, r->feat_dim, stream)) return 1;
+  if (ncp_out && st_nhwc_to_ncp_f32(wide[cur], ncp_out, dt, B, h * w, r->feat_dim, stream)) return 1;
+
+  if (train) {
+    hipLaunchKernelGGL(bn_update_all_kernel, dim3((total + 255) / 256), dim3(256), 0, st, stats, bn_running_mean,
+                       bn_running_var, total, momentum, tab);
+    ST_LAUNCH_CHECK();
+  }
+  return 0;
+}
