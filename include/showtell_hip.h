@@ -134,6 +134,86 @@ int st_resnet_forward(const st_resnet* r, const float* images_nchw, int B, int H
                       void* feat_nhwc_out, void* pooled_out, int pooled_dtype, float* ncp_out,
                       void* stream);
 
+int st_cast2d(const void* x, void* y, int from_dtype, int to_dtype, int rows, int cols, int ldx, int ldy, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Teacher-forced recurrent decoder over a packed sequence.
+ * Replaces RNN.forward (rnn.py:27-35; LSTM/rnn_lstm.py:25-33): nn.Embedding + cat +
+ * pack_padded_sequence + nn.GRU/nn.LSTM (cuDNN fused RNN) + nn.Linear, and the autograd
+ * backward of the same graph (main.py:151).
+ * Rows are time-major packed as pack_padded_sequence orders them: row(t,b) = off[t] + b.
+ *   rows_b/rows_t: (b, t) of every packed row; prev_row: index of row(t-1,b) (unused for t=0).
+ *   batch_sizes_host: HOST array, non-increasing (captions sorted by length, utils.py:66).
+ * Weights are [G*H][in] / [G*H][H] in `dtype` (gate order r,z,n / i,f,g,o as torch), biases fp32.
+ * The workspace carries the saved activations from st_rnn_forward to st_rnn_backward.
+ * st_rnn_forward: logits[ntok][ldl] (optional) and targets[ntok] = caption[b][t] (main.py:145).
+ * st_rnn_backward: gradients are ACCUMULATED (+=) into the fp32 buffers of st_rnn_grads;
+ *   dlogits is [ntok][ldd] in `dtype` with ldd a multiple of 8 and zero pad columns;
+ *   dfeat[B][E] (fp32) receives the gradient w.r.t. the image feature rows.
+ * ---------------------------------------------------------------------------------- */
+#define ST_MAX_LAYERS 8
+typedef struct {
+  int cell, dtype, L, in0, H, V, E;
+  const void* emb;                                   /* [V][E] dtype                  */
+  const void* w_ih[ST_MAX_LAYERS]; const void* w_hh[ST_MAX_LAYERS];
+  const float* b_ih[ST_MAX_LAYERS]; const float* b_hh[ST_MAX_LAYERS];
+  const void* w_lin; const float* b_lin;             /* [V][H] dtype, [V] fp32        */
+} st_rnn_params;
+
+typedef struct {
+  float* emb;
+  float* w_ih[ST_MAX_LAYERS]; float* w_hh[ST_MAX_LAYERS]; float* b_ih[ST_MAX_LAYERS]; float* b_hh[ST_MAX_LAYERS];
+  float* w_lin; float* b_lin;
+} st_rnn_grads;
+
+typedef struct {
+  int B, T, ntok, Tcap;
+  const int* batch_sizes_host;
+  const int* rows_b; const int* rows_t; const int* prev_row;   /* device int32 [ntok] */
+  const long* caption;                                          /* device int64 [B][Tcap] */
+} st_packed_seq;
+
+size_t st_rnn_workspace_bytes(const st_rnn_params* p, const st_packed_seq* s);
+int st_rnn_forward(const st_rnn_params* p, const st_packed_seq* s, const void* x0_override, const void* feat,
+                   void* workspace, size_t workspace_bytes, void* logits, int logits_dtype, int ldl,
+                   long* targets, int save_for_backward, void* stream);
+int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, const st_packed_seq* s,
+                    const void* x0_override, const void* dlogits, int ldd, const float* dy_top,
+                    void* workspace, size_t workspace_bytes, float* dfeat, float* dx0_out, void* stream);
+
+/* nn.CrossEntropyLoss() (mean) forward + backward (main.py:94,149):
+ *   *loss_accum += mean_r( logsumexp(x_r) - x_r[target_r] );  dlogits = (softmax - onehot) * grad_scale / rows
+ * dlogits may alias logits when the dtypes match; pad columns [V, ldd) are zero-filled. */
+int st_cross_entropy(const void* logits, int logits_dtype, const long* target, int rows, int V, int ldl,
+                     float* loss_accum, void* dlogits, int dlogits_dtype, int ldd, float grad_scale,
+                     const float* grad_scale_dev /* optional device scalar multiplied in */, void* stream);
+
+/* Encoder head: y = BatchNorm1d(x W^T + b) (cnn.py:37-38,49; momentum 0.01) and its backward
+ * (dx is not needed: the backbone output is detached, cnn.py:47).  Gradients are accumulated. */
+size_t st_head_workspace_bytes(int B, int F, int E, int dtype);
+int st_linear_bn1d_forward(const void* x, const void* w, const float* bias, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int B, int F, int E, int dtype,
+                           int train, float momentum, float eps,
+                           float* z_out, float* save_mean, float* save_rstd, void* y_dtype, float* y_f32, void* stream);
+int st_linear_bn1d_backward(const float* dy, const float* z, const void* x, const float* gamma,
+                            const float* save_mean, const float* save_rstd, int B, int F, int E, int dtype, int train,
+                            float* dw, float* dbias, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
+/* torch.optim.SGD(lr, momentum) / torch.optim.Adam(lr) (main.py:97-100,152) over one flat fp32
+ * buffer; bf16_shadow (optional) receives the updated parameters rounded to bf16. */
+int st_sgd_step(float* param, const float* grad, float* momentum_buf, void* bf16_shadow, long n,
+                float lr, float momentum, int first_step, float grad_scale, void* stream);
+int st_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* bf16_shadow, long n,
+                 float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* Greedy decoding, exactly `steps` iterations with no early stop (rnn.py:37-58, rnn_lstm.py:35-57):
+ * ids_out[B][steps] int64 (first-maximum tie rule of torch.max).  logits_out (optional, tests):
+ * [steps][B][Vp] fp32 with Vp = V rounded up to 8. */
+size_t st_rnn_greedy_workspace_bytes(const st_rnn_params* p, int B);
+int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, int steps, void* workspace, size_t workspace_bytes,
+                  long* ids_out, float* logits_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

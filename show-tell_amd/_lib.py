@@ -29,6 +29,25 @@ class BnActDesc(C.Structure):
                 ("dtype", c_i), ("rows", c_l), ("C", c_i), ("count", c_f), ("eps", c_f), ("relu", c_i)]
 
 
+ST_MAX_LAYERS = 8
+
+
+class RnnParams(C.Structure):
+    _fields_ = [("cell", c_i), ("dtype", c_i), ("L", c_i), ("in0", c_i), ("H", c_i), ("V", c_i), ("E", c_i),
+                ("emb", c_p), ("w_ih", c_p * ST_MAX_LAYERS), ("w_hh", c_p * ST_MAX_LAYERS),
+                ("b_ih", c_p * ST_MAX_LAYERS), ("b_hh", c_p * ST_MAX_LAYERS), ("w_lin", c_p), ("b_lin", c_p)]
+
+
+class RnnGrads(C.Structure):
+    _fields_ = [("emb", c_p), ("w_ih", c_p * ST_MAX_LAYERS), ("w_hh", c_p * ST_MAX_LAYERS),
+                ("b_ih", c_p * ST_MAX_LAYERS), ("b_hh", c_p * ST_MAX_LAYERS), ("w_lin", c_p), ("b_lin", c_p)]
+
+
+class PackedSeq(C.Structure):
+    _fields_ = [("B", c_i), ("T", c_i), ("ntok", c_i), ("Tcap", c_i), ("batch_sizes_host", C.POINTER(c_i)),
+                ("rows_b", c_p), ("rows_t", c_p), ("prev_row", c_p), ("caption", c_p)]
+
+
 _SIGS = {
     "st_version": ([], c_i),
     "st_conv": ([C.POINTER(ConvDesc), c_p], c_i),
@@ -41,6 +60,19 @@ _SIGS = {
     "st_cast": ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
     "st_transpose": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_pack_conv_weight": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_cast2d": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_rnn_workspace_bytes": ([C.POINTER(RnnParams), C.POINTER(PackedSeq)], C.c_size_t),
+    "st_rnn_forward": ([C.POINTER(RnnParams), C.POINTER(PackedSeq), c_p, c_p, c_p, C.c_size_t, c_p, c_i, c_i, c_p, c_i, c_p], c_i),
+    "st_rnn_backward": ([C.POINTER(RnnParams), C.POINTER(RnnGrads), C.POINTER(PackedSeq), c_p, c_p, c_i, c_p, c_p, C.c_size_t,
+                         c_p, c_p, c_p], c_i),
+    "st_rnn_greedy_workspace_bytes": ([C.POINTER(RnnParams), c_i], C.c_size_t),
+    "st_rnn_greedy": ([C.POINTER(RnnParams), c_p, c_i, c_i, c_p, C.c_size_t, c_p, c_p, c_p], c_i),
+    "st_cross_entropy": ([c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_p], c_i),
+    "st_head_workspace_bytes": ([c_i, c_i, c_i, c_i], C.c_size_t),
+    "st_linear_bn1d_forward": ([c_p] * 7 + [c_i, c_i, c_i, c_i, c_i, c_f, c_f] + [c_p] * 6, c_i),
+    "st_linear_bn1d_backward": ([c_p] * 6 + [c_i, c_i, c_i, c_i, c_i] + [c_p] * 5 + [C.c_size_t, c_p], c_i),
+    "st_sgd_step": ([c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_i, c_f, c_p], c_i),
+    "st_adam_step": ([c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_f, c_p], c_i),
     "st_resnet_create": ([c_i, c_i, C.POINTER(c_p)], c_i),
     "st_resnet_destroy": ([c_p], None),
     "st_resnet_num_convs": ([c_p], c_i),

@@ -206,6 +206,15 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO*
     y[i] = from_f32<TO>(to_f32<TI>(x[i]));
 }
 
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast2d_kernel(const TI* __restrict__ x, TO* __restrict__ y, int rows, int cols, int ldx, int ldy) {
+  const long total = (long)rows * ldy;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / ldy; const int c = (int)(i - r * ldy);
+    y[i] = from_f32<TO>(c < cols ? to_f32<TI>(x[r * ldx + c]) : 0.f);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          int rows, int cols, int ldx, int ldy) {
@@ -336,6 +345,22 @@ extern "C" int st_cast(const void* x, void* y, int from_dtype, int to_dtype, lon
   else if (from_dtype == ST_BF16 && to_dtype == ST_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (float*)y, n);
   else if (from_dtype == ST_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, n);
   else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_cast2d(const void* x, void* y, int from_dtype, int to_dtype, int rows, int cols, int ldx, int ldy, void* stream) {
+  ST_CHECK(x && y, "st_cast2d: null pointer");
+  ST_DT_CHECK(from_dtype, "st_cast2d");
+  ST_DT_CHECK(to_dtype, "st_cast2d");
+  ST_CHECK(ldx >= cols && ldy >= cols, "st_cast2d: leading dimensions too small");
+  if (rows <= 0) return 0;
+  const int grid = grid_for((long)rows * ldy, 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (from_dtype == ST_F32 && to_dtype == ST_BF16) hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)x, (bf16_t*)y, rows, cols, ldx, ldy);
+  else if (from_dtype == ST_BF16 && to_dtype == ST_F32) hipLaunchKernelGGL((cast2d_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (float*)y, rows, cols, ldx, ldy);
+  else if (from_dtype == ST_F32) hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, rows, cols, ldx, ldy);
+  else hipLaunchKernelGGL((cast2d_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, cols, ldx, ldy);
   ST_LAUNCH_CHECK();
   return 0;
 }

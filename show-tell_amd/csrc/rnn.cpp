@@ -1,0 +1,253 @@
+// Teacher-forced decoder (GRU / LSTM over a packed sequence): forward and BPTT backward,
+// each as ONE C-ABI call that issues every kernel of the pass on one stream.
+//
+// Replaces RNN.forward (reference rnn.py:27-35, LSTM/rnn_lstm.py:25-33) and the autograd
+// backward torch builds for it (main.py:151).  Rows are time-major packed exactly as
+// pack_padded_sequence orders them: row(t, b) = step_off[t] + b for b < batch_sizes[t].
+//
+// forward:  x0 = [feat ; emb(caption)] gathered straight into packed rows (no cat/pack copies)
+//           per layer: one MFMA GEMM for all timesteps' input projections, then one fused
+//           launch per timestep (h W_hh^T + gates)            -> st_rnn_forward
+//           logits = y_top W_lin^T + b
+// backward: dlogits -> dW_lin, db_lin, dy_top; per layer (top down) one gate-gradient kernel +
+//           one skinny GEMM per timestep, then three MFMA GEMMs (dW_ih, dW_hh, dx) whose
+//           K-major operands are produced by explicit transposes -> st_rnn_backward
+#include "common.h"
+#include "rnn_kernels.h"
+#include <string.h>
+#include <vector>
+
+namespace {
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+inline int up8(int v) { return (v + 7) & ~7; }
+
+struct Plan {
+  int G, GH, Np, Vp, maxw;
+  size_t es;
+  size_t x0, y, gates, cst, gx, dy0, dy1, dgx, dgh, dhc, dcc, hprev, tA, tB, wT, total;
+};
+
+Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
+  Plan q;
+  q.G = p->cell == ST_CELL_GRU ? 3 : 4;
+  q.GH = q.G * p->H;
+  q.Np = up8(s->ntok);
+  q.Vp = up8(p->V);
+  q.es = st_dtype_size(p->dtype);
+  q.maxw = p->in0 > p->H ? p->in0 : p->H;
+  const size_t n = s->ntok, L = p->L, H = p->H;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+  q.x0 = take(n * p->in0 * q.es);
+  q.y = take(L * n * H * q.es);
+  q.gates = take(L * n * 4 * H * q.es);
+  q.cst = take(p->cell == ST_CELL_LSTM ? L * n * H * q.es : 0);
+  q.gx = take(n * q.GH * q.es);
+  q.dy0 = take(n * q.maxw * sizeof(float));
+  q.dy1 = take(n * q.maxw * sizeof(float));
+  q.dgx = take(n * q.GH * q.es);
+  q.dgh = take(n * q.GH * q.es);
+  q.dhc = take((size_t)s->B * H * sizeof(float));
+  q.dcc = take((size_t)s->B * H * sizeof(float));
+  q.hprev = take(n * H * q.es);
+  // transposed operands: tA <= max(V, GH) x Np ; tB <= max(H, in0) x Np ; wT <= max(H x Vp, maxw x GH)
+  const size_t ra = (size_t)(p->V > q.GH ? p->V : q.GH);
+  q.tA = take(ra * q.Np * q.es);
+  q.tB = take((size_t)q.maxw * q.Np * q.es);
+  const size_t w1 = (size_t)H * q.Vp, w2 = (size_t)q.maxw * q.GH;
+  q.wT = take((w1 > w2 ? w1 : w2) * q.es);
+  q.total = o;
+  return q;
+}
+
+int gemm_nt(const void* a, int lda, const void* w, int ldw, void* y, int ldy, int M, int N, int K, int dtype, int out_dtype,
+            const float* bias, int accumulate, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  st_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.x = a; d.w = w; d.y = y; d.bias = bias; d.dtype = dtype; d.out_dtype = out_dtype;
+  d.B = M; d.Hin = 1; d.Win = 1; d.Cin = K; d.Ho = 1; d.Wo = 1; d.N = N; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+  d.ldx = lda; d.ldw = ldw; d.ldy = ldy; d.accumulate = accumulate;
+  return st_conv(&d, stream);
+}
+
+int check_common(const st_rnn_params* p, const st_packed_seq* s, const char* who) {
+  ST_CHECK(p && s, "%s: null descriptor", who);
+  ST_CHECK(p->cell == ST_CELL_GRU || p->cell == ST_CELL_LSTM, "%s: bad cell %d", who, p->cell);
+  ST_CHECK(p->dtype == ST_F32 || p->dtype == ST_BF16, "%s: bad dtype %d", who, p->dtype);
+  ST_CHECK(p->L >= 1 && p->L <= ST_MAX_LAYERS, "%s: num_layers=%d out of range [1,%d]", who, p->L, ST_MAX_LAYERS);
+  ST_CHECK(p->H % 8 == 0 && p->in0 % 8 == 0 && p->E % 8 == 0, "%s: E=%d, in0=%d and H=%d must be multiples of 8", who, p->E, p->in0, p->H);
+  ST_CHECK(p->V > 0, "%s: bad vocabulary size", who);
+  ST_CHECK(s->B > 0 && s->T > 0 && s->ntok > 0 && s->batch_sizes_host && s->rows_b && s->rows_t && s->prev_row && s->caption,
+           "%s: bad packed-sequence descriptor", who);
+  int sum = 0, prev = s->B;
+  for (int t = 0; t < s->T; ++t) {
+    const int b = s->batch_sizes_host[t];
+    ST_CHECK(b > 0 && b <= prev, "%s: batch_sizes must be positive and non-increasing (captions sorted by length, utils.py:66)", who);
+    prev = b; sum += b;
+  }
+  ST_CHECK(sum == s->ntok && s->batch_sizes_host[0] == s->B, "%s: batch_sizes do not add up to ntok", who);
+  for (int l = 0; l < p->L; ++l)
+    ST_CHECK(p->w_ih[l] && p->w_hh[l] && p->b_ih[l] && p->b_hh[l], "%s: null weights for layer %d", who, l);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t st_rnn_workspace_bytes(const st_rnn_params* p, const st_packed_seq* s) {
+  if (!p || !s) return 0;
+  return make_plan(p, s).total;
+}
+
+extern "C" int st_rnn_forward(const st_rnn_params* p, const st_packed_seq* s, const void* x0_override, const void* feat,
+                              void* workspace, size_t workspace_bytes, void* logits, int logits_dtype, int ldl,
+                              long* targets, int save_for_backward, void* stream) {
+  if (check_common(p, s, "st_rnn_forward")) return 1;
+  ST_CHECK(workspace && (x0_override || (feat && p->emb)), "st_rnn_forward: null pointer");
+  const Plan q = make_plan(p, s);
+  ST_CHECK(workspace_bytes >= q.total, "st_rnn_forward: workspace too small (%zu < %zu)", workspace_bytes, q.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int dt = p->dtype, H = p->H, n = s->ntok;
+  const size_t es = q.es;
+
+  const void* x0 = x0_override;
+  if (!x0) {
+    ST_CHECK(p->in0 == p->E, "st_rnn_forward: in0 != E needs x0_override");
+    if (pack_inputs_launch(feat, p->emb, s->caption, s->Tcap, s->rows_b, s->rows_t, ws + q.x0, targets, n, p->E, p->V, 0, dt, st)) return 1;
+    x0 = ws + q.x0;
+  }
+  std::vector<int> off(s->T + 1, 0);
+  for (int t = 0; t < s->T; ++t) off[t + 1] = off[t] + s->batch_sizes_host[t];
+
+  for (int l = 0; l < p->L; ++l) {
+    const void* xl = l == 0 ? x0 : ws + q.y + (size_t)(l - 1) * n * H * es;
+    const int in = l == 0 ? p->in0 : H;
+    char* yl = ws + q.y + (size_t)l * n * H * es;
+    char* gl = ws + q.gates + (size_t)l * n * 4 * H * es;
+    char* cl = ws + q.cst + (size_t)l * n * H * es;
+    if (gemm_nt(xl, in, p->w_ih[l], in, ws + q.gx, q.GH, n, q.GH, in, dt, dt, p->b_ih[l], 0, stream)) return 1;
+    for (int t = 0; t < s->T; ++t) {
+      const int bt = s->batch_sizes_host[t];
+      RnnGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.M = bt; a.N = H; a.K = H; a.lda = H; a.ldw = H; a.gstride = H;
+      a.W = p->w_hh[l];
+      a.A = t > 0 ? yl + (size_t)off[t - 1] * H * es : nullptr;
+      a.hprev = a.A; a.ldhp = H;
+      a.bias_h = p->b_hh[l];
+      a.gx = ws + q.gx + (size_t)off[t] * q.GH * es; a.ldgx = q.GH;
+      a.hout = yl + (size_t)off[t] * H * es; a.ldho = H;
+      if (save_for_backward) { a.cache = gl + (size_t)off[t] * 4 * H * es; a.ldcache = 4 * H; }
+      if (p->cell == ST_CELL_LSTM) {
+        a.cprev = t > 0 ? cl + (size_t)off[t - 1] * H * es : nullptr;
+        a.cout = cl + (size_t)off[t] * H * es;
+      }
+      if (rnn_gemm_launch(a, dt, p->cell == ST_CELL_GRU ? 1 : 2, 0, st)) return 1;
+    }
+  }
+  if (logits) {
+    ST_CHECK(p->w_lin && p->b_lin, "st_rnn_forward: logits requested without the vocabulary projection");
+    const char* ytop = ws + q.y + (size_t)(p->L - 1) * n * H * es;
+    if (gemm_nt(ytop, H, p->w_lin, H, logits, ldl, n, p->V, H, dt, logits_dtype, p->b_lin, 0, stream)) return 1;
+  }
+  return 0;
+}
+
+extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, const st_packed_seq* s,
+                               const void* x0_override, const void* dlogits, int ldd, const float* dy_top_extra,
+                               void* workspace, size_t workspace_bytes, float* dfeat, float* dx0_out, void* stream) {
+  if (check_common(p, s, "st_rnn_backward")) return 1;
+  ST_CHECK(g && workspace, "st_rnn_backward: null pointer");
+  const Plan q = make_plan(p, s);
+  ST_CHECK(workspace_bytes >= q.total, "st_rnn_backward: workspace too small (%zu < %zu)", workspace_bytes, q.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int dt = p->dtype, H = p->H, n = s->ntok, Np = q.Np, GH = q.GH;
+  const size_t es = q.es;
+  std::vector<int> off(s->T + 1, 0);
+  for (int t = 0; t < s->T; ++t) off[t + 1] = off[t] + s->batch_sizes_host[t];
+  float* dy = reinterpret_cast<float*>(ws + q.dy0);
+  float* dx = reinterpret_cast<float*>(ws + q.dy1);
+  const char* ytop = ws + q.y + (size_t)(p->L - 1) * n * H * es;
+
+  if (dlogits) {
+    ST_CHECK(p->w_lin && g->w_lin && g->b_lin, "st_rnn_backward: vocabulary projection gradients requested without buffers");
+    ST_CHECK(ldd >= q.Vp && ldd % 8 == 0, "st_rnn_backward: dlogits leading dimension %d must be a multiple of 8 and >= %d", ldd, q.Vp);
+    // db = colsum(dlogits);  dW_lin += dlogits^T y_top;  dy_top = dlogits W_lin
+    if (colsum_launch(dlogits, g->b_lin, n, p->V, ldd, dt, st)) return 1;
+    if (st_transpose(dlogits, ws + q.tA, dt, n, p->V, ldd, Np, stream)) return 1;
+    if (st_transpose(ytop, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
+    if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_lin, H, p->V, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
+    if (st_transpose(p->w_lin, ws + q.wT, dt, p->V, H, H, q.Vp, stream)) return 1;
+    if (gemm_nt(dlogits, ldd, ws + q.wT, q.Vp, dy, H, n, H, q.Vp, dt, ST_F32, nullptr, 0, stream)) return 1;
+    if (dy_top_extra) { st_set_error("st_rnn_backward: dlogits and dy_top_extra are exclusive"); return 1; }
+  } else {
+    ST_CHECK(dy_top_extra, "st_rnn_backward: need dlogits or dy_top");
+    if (hipMemcpyAsync(dy, dy_top_extra, (size_t)n * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      st_set_error("st_rnn_backward: copy failed"); return 1;
+    }
+  }
+
+  const void* x0 = x0_override ? x0_override : ws + q.x0;
+  for (int l = p->L - 1; l >= 0; --l) {
+    const int in = l == 0 ? p->in0 : H;
+    const char* xl = l == 0 ? reinterpret_cast<const char*>(x0) : ws + q.y + (size_t)(l - 1) * n * H * es;
+    char* yl = ws + q.y + (size_t)l * n * H * es;
+    char* gl = ws + q.gates + (size_t)l * n * 4 * H * es;
+    char* cl = ws + q.cst + (size_t)l * n * H * es;
+    float* dhc = reinterpret_cast<float*>(ws + q.dhc);
+    float* dcc = reinterpret_cast<float*>(ws + q.dcc);
+    if (hipMemsetAsync(dhc, 0, (size_t)s->B * H * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(dcc, 0, (size_t)s->B * H * sizeof(float), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
+    // W_hh^T [H][GH]: K-major operand of dh_{t-1} += dgh_t W_hh
+    if (st_transpose(p->w_hh[l], ws + q.wT, dt, GH, H, H, GH, stream)) return 1;
+    char* dgx = ws + q.dgx;
+    char* dgh = p->cell == ST_CELL_GRU ? ws + q.dgh : ws + q.dgx;   // LSTM: the same gradient feeds both projections
+    for (int t = s->T - 1; t >= 0; --t) {
+      const int bt = s->batch_sizes_host[t];
+      const void* hprev = t > 0 ? yl + (size_t)off[t - 1] * H * es : nullptr;
+      if (p->cell == ST_CELL_GRU) {
+        if (gru_bwd_gates_launch(dy + (size_t)off[t] * H, dhc, gl + (size_t)off[t] * 4 * H * es, hprev,
+                                 dgx + (size_t)off[t] * GH * es, dgh + (size_t)off[t] * GH * es, bt, H, dt, st)) return 1;
+      } else {
+        const void* cprev = t > 0 ? cl + (size_t)off[t - 1] * H * es : nullptr;
+        if (lstm_bwd_gates_launch(dy + (size_t)off[t] * H, dhc, dcc, gl + (size_t)off[t] * 4 * H * es,
+                                  cl + (size_t)off[t] * H * es, cprev, dgx + (size_t)off[t] * GH * es, bt, H, dt, st)) return 1;
+      }
+      if (t > 0) {
+        RnnGemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.A = dgh + (size_t)off[t] * GH * es; a.W = ws + q.wT; a.M = bt; a.N = H; a.K = GH; a.lda = GH; a.ldw = GH; a.gstride = 0;
+        a.out_f32 = dhc; a.ldo = H; a.accumulate = 1;
+        if (rnn_gemm_launch(a, dt, 0, 0, st)) return 1;
+      }
+    }
+    // parameter gradients of this layer
+    if (colsum_launch(dgx, g->b_ih[l], n, GH, GH, dt, st)) return 1;
+    if (colsum_launch(dgh, g->b_hh[l], n, GH, GH, dt, st)) return 1;
+    if (st_transpose(dgx, ws + q.tA, dt, n, GH, GH, Np, stream)) return 1;
+    if (st_transpose(xl, ws + q.tB, dt, n, in, in, Np, stream)) return 1;
+    if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_ih[l], in, GH, in, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
+    if (gather_hprev_launch(yl, s->rows_t, s->prev_row, ws + q.hprev, n, H, dt, st)) return 1;
+    if (p->cell == ST_CELL_GRU && st_transpose(dgh, ws + q.tA, dt, n, GH, GH, Np, stream)) return 1;
+    if (st_transpose(ws + q.hprev, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
+    if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_hh[l], H, GH, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
+    // dx_l = dgx W_ih  -> gradient w.r.t. the layer below (fp32)
+    if (l > 0 || dfeat || dx0_out || g->emb) {
+      if (st_transpose(p->w_ih[l], ws + q.wT, dt, GH, in, in, GH, stream)) return 1;
+      float* dst = (l == 0 && dx0_out) ? dx0_out : dx;
+      if (gemm_nt(dgx, GH, ws + q.wT, GH, dst, in, n, in, GH, dt, ST_F32, nullptr, 0, stream)) return 1;
+      if (l == 0) {
+        if (!x0_override) {
+          ST_CHECK(g->emb, "st_rnn_backward: embedding gradient buffer missing");
+          if (embedding_bwd_launch(dst, s->caption, s->Tcap, s->rows_b, s->rows_t, dfeat, g->emb, n, p->E, p->V, 0, st)) return 1;
+        }
+      } else {
+        float* tmp = dy; dy = dx; dx = tmp;
+      }
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,30 @@
+// Internal (non-ABI) launch interface of the recurrent-decoder kernels.
+#pragma once
+#include "common.h"
+
+struct RnnGemmArgs {
+  // acc[g][m][n] = sum_k A[m][k] W[g*gstride + n][k]  (+ second operand pair A2/W2 when HAS_X)
+  const void* A; const void* W; int M, N, K, lda, ldw, gstride;
+  const void* A2; const void* W2; int K2, lda2, ldw2;
+  // EPI 0
+  float* out_f32; int ldo; int accumulate;
+  // gate epilogues
+  const float* bias_h; const float* bias_x;
+  const void* gx; int ldgx;            // precomputed x-projection (+b_ih) rows of this step
+  const void* hprev; const void* cprev; int ldhp;
+  void* hout; void* cout; int ldho;
+  void* hout2; int ldho2;              // optional second copy of h' (decode: running state + layer output)
+  void* cache; int ldcache;            // saved gates for BPTT (NULL at inference)
+};
+
+int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st);
+int pack_inputs_launch(const void* feat, const void* emb, const long* cap, int Tcap, const int* rows_b, const int* rows_t,
+                       void* x0, long* target, int ntok, int E, int V, int mode, int dtype, hipStream_t st);
+int embedding_bwd_launch(const float* dx0, const long* cap, int Tcap, const int* rows_b, const int* rows_t,
+                         float* dfeat, float* demb, int ntok, int E, int V, int mode, hipStream_t st);
+int gather_hprev_launch(const void* y, const int* rows_t, const int* prev_row, void* hp, int ntok, int H, int dtype, hipStream_t st);
+int gru_bwd_gates_launch(const float* dy, float* dhc, const void* cache, const void* hprev, void* dgx, void* dgh,
+                         int Bt, int H, int dtype, hipStream_t st);
+int lstm_bwd_gates_launch(const float* dy, float* dhc, float* dcc, const void* cache, const void* cnew, const void* cprev,
+                          void* dg, int Bt, int H, int dtype, hipStream_t st);
+int colsum_launch(const void* x, float* out, int rows, int cols, int ldx, int dtype, hipStream_t st);

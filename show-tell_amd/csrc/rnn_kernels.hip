@@ -1,0 +1,485 @@
+// Recurrent-decoder kernels for gfx950: packed-sequence input gather, the per-timestep
+// "skinny" MFMA GEMM with fused GRU / LSTM gate epilogues, the BPTT gate-gradient kernels,
+// embedding scatter-add, cross-entropy, column sums.
+//
+// Replaces what the reference delegates to cuDNN's fused RNN and to torch ops:
+//   rnn.py:29-31   embedding + cat + pack_padded_sequence      -> pack_inputs_kernel
+//   rnn.py:32      nn.GRU over a PackedSequence (fwd + autograd) -> rnn_gemm_kernel<GRU_*>, gru_bwd_gates_kernel
+//   rnn_lstm.py:30 nn.LSTM                                       -> rnn_gemm_kernel<LSTM_*>, lstm_bwd_gates_kernel
+//   main.py:149    nn.CrossEntropyLoss (fwd + bwd)               -> ce_kernel
+//
+// The recurrent product h_{t-1} W_hh^T has only B_t <= batch rows, so it is launch/latency
+// bound, not FLOP bound: one block owns 16 hidden units (all gates of those units) x 64 batch
+// rows, operands go straight from L2 to MFMA fragments (no LDS: each fragment is used once),
+// and the whole gate nonlinearity runs in the epilogue so a timestep is ONE launch.
+#include "common.h"
+#include "rnn_kernels.h"
+
+namespace {
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<float> {
+  static constexpr int EPC = 4;
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+// 4 consecutive elements of T <-> 4 floats
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
+  const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
+  const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+  v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+  v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) {
+  *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------
+// skinny GEMM  acc[g][m][n] = sum_k A[m][k] * W[g*gstride + n][k]   (+ optional second pair)
+// ---------------------------------------------------------------------------------------
+template <typename T, int NG, bool HAS_X>
+__device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0, int r16, int q4,
+                                           f32x4 (&accH)[NG], f32x4 (&accX)[NG]) {
+  constexpr int EPC = Mfma<T>::EPC;
+  const int m = m0 + r16, n = n0 + r16;
+  const bool mok = m < a.M, nok = n < a.N;
+  auto pass = [&](const void* Ap, const void* Wp, int K, int lda, int ldw, f32x4 (&acc)[NG]) {
+    if (!Ap) return;
+    const T* A = reinterpret_cast<const T*>(Ap) + (long)m * lda;
+    const T* W = reinterpret_cast<const T*>(Wp) + (long)n * ldw;
+    const long gs = (long)a.gstride * ldw;
+    const int nsteps = (K + 4 * EPC - 1) / (4 * EPC);
+    for (int s = 0; s < nsteps; ++s) {
+      const int k = (s * 4 + q4) * EPC;
+      const bool kok = k < K;
+      u32x4 fa = {0u, 0u, 0u, 0u};
+      if (mok && kok) fa = *reinterpret_cast<const u32x4*>(A + k);
+      u32x4 fw[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        fw[g] = u32x4{0u, 0u, 0u, 0u};
+        if (nok && kok) fw[g] = *reinterpret_cast<const u32x4*>(W + g * gs + k);
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) Mfma<T>::run(fw[g], fa, acc[g]);
+    }
+  };
+  pass(a.A, a.W, a.K, a.lda, a.ldw, accH);
+  if (HAS_X) pass(a.A2, a.W2, a.K2, a.lda2, a.ldw2, accX);
+}
+
+// EPI 0: out_f32[m][n] (+)= acc (+bias)         (BPTT dh += dgh W_hh, generic small products)
+// EPI 1: GRU gates (training fwd with precomputed gx, or decode with fused x-projection)
+// EPI 2: LSTM gates
+template <typename T, int NG, int EPI, bool HAS_X>
+__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmArgs a) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64 + wid * 16;
+  if (m0 >= a.M) return;
+  f32x4 accH[NG], accX[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) { accH[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accX[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  skinny_mma<T, NG, HAS_X>(a, m0, n0, r16, q4, accH, accX);
+
+  // lane owns row m = m0 + r16 and units n = n0 + 4*q4 + {0..3}
+  const int m = m0 + r16, n = n0 + 4 * q4;
+  if (m >= a.M || n >= a.N) return;
+  const int H = a.N;
+  if (EPI == 0) {
+    float* o = a.out_f32 + (long)m * a.ldo + n;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = accH[0][e] + (a.bias_h ? a.bias_h[n + e] : 0.f) + (a.accumulate ? o[e] : 0.f);
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+  } else if (EPI == 1) {
+    // r,z,n order (torch.nn.GRU): r = s(xr+hr), z = s(xz+hz), n = tanh(xn + r*(hn)), h' = (1-z) n + z h
+    float xg[3][4], hp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      if (HAS_X) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xg[g][e] = accX[g][e] + a.bias_x[g * H + n + e];
+      } else {
+        load4<T>(reinterpret_cast<const T*>(a.gx) + (long)m * a.ldgx + g * H + n, xg[g]);  // already holds b_ih
+      }
+    }
+    if (a.hprev) load4<T>(reinterpret_cast<const T*>(a.hprev) + (long)m * a.ldhp + n, hp);
+    float hn[4], r[4], z[4], nn[4], hnew[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float hr = accH[0][e] + a.bias_h[n + e], hz = accH[1][e] + a.bias_h[H + n + e];
+      hn[e] = accH[2][e] + a.bias_h[2 * H + n + e];
+      r[e] = sigm(xg[0][e] + hr);
+      z[e] = sigm(xg[1][e] + hz);
+      nn[e] = tanhf(xg[2][e] + r[e] * hn[e]);
+      hnew[e] = (1.f - z[e]) * nn[e] + z[e] * hp[e];
+    }
+    store4<T>(reinterpret_cast<T*>(a.hout) + (long)m * a.ldho + n, hnew);
+    if (a.hout2) store4<T>(reinterpret_cast<T*>(a.hout2) + (long)m * a.ldho2 + n, hnew);
+    if (a.cache) {
+      T* c = reinterpret_cast<T*>(a.cache) + (long)m * a.ldcache + n;
+      store4<T>(c, r); store4<T>(c + H, z); store4<T>(c + 2 * H, nn); store4<T>(c + 3 * H, hn);
+    }
+  } else {
+    // i,f,g,o order (torch.nn.LSTM): c' = f c + i g ; h' = o tanh(c')
+    float pre[4][4], cp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (HAS_X) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre[g][e] = accX[g][e] + a.bias_x[g * H + n + e];
+      } else {
+        load4<T>(reinterpret_cast<const T*>(a.gx) + (long)m * a.ldgx + g * H + n, pre[g]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pre[g][e] += accH[g][e] + a.bias_h[g * H + n + e];
+    }
+    if (a.cprev) load4<T>(reinterpret_cast<const T*>(a.cprev) + (long)m * a.ldhp + n, cp);
+    float ig[4], fg[4], gg[4], og[4], cn[4], hnew[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ig[e] = sigm(pre[0][e]); fg[e] = sigm(pre[1][e]); gg[e] = tanhf(pre[2][e]); og[e] = sigm(pre[3][e]);
+      cn[e] = fg[e] * cp[e] + ig[e] * gg[e];
+      hnew[e] = og[e] * tanhf(cn[e]);
+    }
+    store4<T>(reinterpret_cast<T*>(a.hout) + (long)m * a.ldho + n, hnew);
+    if (a.hout2) store4<T>(reinterpret_cast<T*>(a.hout2) + (long)m * a.ldho2 + n, hnew);
+    store4<T>(reinterpret_cast<T*>(a.cout) + (long)m * a.ldho + n, cn);
+    if (a.cache) {
+      T* c = reinterpret_cast<T*>(a.cache) + (long)m * a.ldcache + n;
+      store4<T>(c, ig); store4<T>(c + H, fg); store4<T>(c + 2 * H, gg); store4<T>(c + 3 * H, og);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// packed input rows: x0[row(t,b)] = t == 0 ? feat[b] : emb[caption[b][t-1]]   (rnn.py:29-31)
+//                    target[row(t,b)] = caption[b][t]                          (main.py:145)
+// mode 1 (attention decoder, rnn_attn.py:70): x0[row] = emb[caption[b][t]]
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_inputs_kernel(const T* __restrict__ feat, const T* __restrict__ emb,
+                                                          const long* __restrict__ cap, int Tcap,
+                                                          const int* __restrict__ rows_b, const int* __restrict__ rows_t,
+                                                          T* __restrict__ x0, long* __restrict__ target,
+                                                          int ntok, int E, int V, int mode) {
+  constexpr int N = 16 / (int)sizeof(T);
+  const int cpr = E / N;
+  const long total = (long)ntok * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / cpr), c = (int)(i - (long)row * cpr) * N;
+    const int b = rows_b[row], t = rows_t[row];
+    const T* src;
+    if (mode == 0 && t == 0) src = feat + (long)b * E + c;
+    else {
+      long tok = cap[(long)b * Tcap + (mode == 0 ? t - 1 : t)];
+      tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);   // keep a corrupt id from faulting the GPU
+      src = emb + tok * E + c;
+    }
+    *reinterpret_cast<u32x4*>(x0 + (long)row * E + c) = *reinterpret_cast<const u32x4*>(src);
+    if (c == 0 && target) target[row] = cap[(long)b * Tcap + t];
+  }
+}
+
+// dX0 rows -> dfeat (t == 0, plain store) and dEmb (t >= 1, fp32 atomics; 256 contiguous bytes per wave-instruction)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dx0, const long* __restrict__ cap, int Tcap,
+                                                            const int* __restrict__ rows_b, const int* __restrict__ rows_t,
+                                                            float* __restrict__ dfeat, float* __restrict__ demb,
+                                                            int ntok, int E, int V, int mode) {
+  const long total = (long)ntok * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / E), c = (int)(i - (long)row * E);
+    const int b = rows_b[row], t = rows_t[row];
+    const float v = dx0[i];
+    if (mode == 0 && t == 0) { if (dfeat) dfeat[(long)b * E + c] = v; }
+    else {
+      long tok = cap[(long)b * Tcap + (mode == 0 ? t - 1 : t)];
+      tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+      atomicAdd(demb + tok * E + c, v);
+    }
+  }
+}
+
+// hprev[row(t,b)] = t == 0 ? h0 : y[row(t-1,b)]   (operand of dW_hh = sum_t dgh_t^T h_{t-1})
+template <typename T>
+__global__ __launch_bounds__(256) void gather_hprev_kernel(const T* __restrict__ y, const int* __restrict__ rows_t,
+                                                           const int* __restrict__ prev_row, T* __restrict__ hp, int ntok, int H) {
+  constexpr int N = 16 / (int)sizeof(T);
+  const int cpr = H / N;
+  const long total = (long)ntok * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / cpr), c = (int)(i - (long)row * cpr) * N;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (rows_t[row] > 0) v = *reinterpret_cast<const u32x4*>(y + (long)prev_row[row] * H + c);
+    *reinterpret_cast<u32x4*>(hp + (long)row * H + c) = v;
+  }
+}
+
+// GRU BPTT gate gradients for the B_t rows of one timestep (see DESIGN.md for the algebra)
+template <typename T>
+__global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const float* __restrict__ dy, float* __restrict__ dhc,
+                                                            const T* __restrict__ cache, const T* __restrict__ hprev,
+                                                            T* __restrict__ dgx, T* __restrict__ dgh, int Bt, int H) {
+  const int total = Bt * (H / 4);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = i / (H / 4), j = (i - b * (H / 4)) * 4;
+  float g[4], c[4], r[4], z[4], n[4], hn[4], hp[4] = {0.f, 0.f, 0.f, 0.f};
+  load4<float>(dy + (long)b * H + j, g);
+  load4<float>(dhc + (long)b * H + j, c);
+  const T* cr = cache + (long)b * 4 * H + j;
+  load4<T>(cr, r); load4<T>(cr + H, z); load4<T>(cr + 2 * H, n); load4<T>(cr + 3 * H, hn);
+  if (hprev) load4<T>(hprev + (long)b * H + j, hp);
+  float drp[4], dzp[4], dnp[4], dnr[4], dhz[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float dh = g[e] + c[e];
+    const float dn = dh * (1.f - z[e]);
+    const float dz = dh * (hp[e] - n[e]);
+    dnp[e] = dn * (1.f - n[e] * n[e]);
+    drp[e] = dnp[e] * hn[e] * r[e] * (1.f - r[e]);
+    dzp[e] = dz * z[e] * (1.f - z[e]);
+    dnr[e] = dnp[e] * r[e];
+    dhz[e] = dh * z[e];
+  }
+  T* ox = dgx + (long)b * 3 * H + j;
+  T* oh = dgh + (long)b * 3 * H + j;
+  store4<T>(ox, drp); store4<T>(ox + H, dzp); store4<T>(ox + 2 * H, dnp);
+  store4<T>(oh, drp); store4<T>(oh + H, dzp); store4<T>(oh + 2 * H, dnr);
+  store4<float>(dhc + (long)b * H + j, dhz);
+}
+
+// LSTM BPTT gate gradients: dg is shared by the x- and h-projections (all four gates are sums)
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const float* __restrict__ dy, float* __restrict__ dhc, float* __restrict__ dcc,
+                                                             const T* __restrict__ cache, const T* __restrict__ cnew, const T* __restrict__ cprev,
+                                                             T* __restrict__ dg, int Bt, int H) {
+  const int total = Bt * (H / 4);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = i / (H / 4), j = (i - b * (H / 4)) * 4;
+  float g[4], ch[4], cc[4], ig[4], fg[4], gg[4], og[4], cn[4], cp[4] = {0.f, 0.f, 0.f, 0.f};
+  load4<float>(dy + (long)b * H + j, g);
+  load4<float>(dhc + (long)b * H + j, ch);
+  load4<float>(dcc + (long)b * H + j, cc);
+  const T* cr = cache + (long)b * 4 * H + j;
+  load4<T>(cr, ig); load4<T>(cr + H, fg); load4<T>(cr + 2 * H, gg); load4<T>(cr + 3 * H, og);
+  load4<T>(cnew + (long)b * H + j, cn);
+  if (cprev) load4<T>(cprev + (long)b * H + j, cp);
+  float di[4], df[4], dgg[4], dob[4], dcp[4], zero[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float dh = g[e] + ch[e];
+    const float tc = tanhf(cn[e]);
+    const float dc = cc[e] + dh * og[e] * (1.f - tc * tc);
+    dob[e] = dh * tc * og[e] * (1.f - og[e]);
+    di[e] = dc * gg[e] * ig[e] * (1.f - ig[e]);
+    df[e] = dc * cp[e] * fg[e] * (1.f - fg[e]);
+    dgg[e] = dc * ig[e] * (1.f - gg[e] * gg[e]);
+    dcp[e] = dc * fg[e];
+  }
+  T* o = dg + (long)b * 4 * H + j;
+  store4<T>(o, di); store4<T>(o + H, df); store4<T>(o + 2 * H, dgg); store4<T>(o + 3 * H, dob);
+  store4<float>(dcc + (long)b * H + j, dcp);
+  store4<float>(dhc + (long)b * H + j, zero);   // dh_{t-1} is entirely the GEMM term, accumulated next
+}
+
+// ---------------------------------------------------------------------------------------
+// cross entropy over rows (mean reduction):  loss += -log softmax(x)[t] / nrows
+// dlogits = (softmax - onehot) * gscale   written in TD (may alias the logits when TD == TL)
+// one block per row; the row is read twice from L2 (max+sum online, then gradient)
+// ---------------------------------------------------------------------------------------
+template <typename TL, typename TD>
+__global__ __launch_bounds__(256) void ce_kernel(const TL* __restrict__ logits, const long* __restrict__ target,
+                                                 float* __restrict__ loss, TD* __restrict__ dlogits,
+                                                 int V, int ldl, int ldd, float inv_rows, float gscale, const float* __restrict__ gscale_dev) {
+  __shared__ float sm[8], ss[8];
+  const int row = blockIdx.x;
+  const TL* x = logits + (long)row * ldl;
+  float m = -INFINITY, s = 0.f;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    const float v = to_f32<TL>(x[i]);
+    const float nm = fmaxf(m, v);
+    s = s * __expf(m - nm) + __expf(v - nm);
+    m = nm;
+  }
+  // combine (m, s) pairs across the wave, then across waves
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
+    const float nm = fmaxf(m, om);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+    m = nm;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sm[wid] = m; ss[wid] = s; }
+  __syncthreads();
+  float M = sm[0], S = ss[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+    const float nm = fmaxf(M, sm[w]);
+    S = S * __expf(M - nm) + ss[w] * __expf(sm[w] - nm);
+    M = nm;
+  }
+  long t = target[row];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  const float lse = M + __logf(S);
+  const float xt = to_f32<TL>(x[t]);
+  __syncthreads();   // dlogits may alias the logits: every read of x[t] happens before any write
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, (lse - xt) * inv_rows);
+  if (dlogits) {
+    if (gscale_dev) gscale *= *gscale_dev;
+    TD* d = dlogits + (long)row * ldd;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+      const float p = __expf(to_f32<TL>(x[i]) - lse);
+      d[i] = from_f32<TD>((p - (i == t ? 1.f : 0.f)) * gscale);
+    }
+    for (int i = V + threadIdx.x; i < ldd; i += blockDim.x) d[i] = from_f32<TD>(0.f);   // pad columns feed GEMMs as K
+  }
+}
+
+// out[n] += sum_rows x[row][n]      (bias gradients); one thread per column, coalesced over n
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int cols, int ldx, int rows_per_block) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= cols) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += to_f32<T>(x[(long)r * ldx + n]);
+  atomicAdd(out + n, s);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// internal launchers (declared in rnn_kernels.h)
+// ---------------------------------------------------------------------------------------
+int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st) {
+  if (a.M <= 0) return 0;
+  ST_CHECK(a.N % 4 == 0, "rnn_gemm: N=%d must be a multiple of 4", a.N);
+  const int epc = dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(a.K % epc == 0 && a.lda % epc == 0 && a.ldw % epc == 0, "rnn_gemm: K/lda/ldw must be multiples of %d", epc);
+  if (has_x) ST_CHECK(a.K2 % epc == 0 && a.lda2 % epc == 0 && a.ldw2 % epc == 0, "rnn_gemm: K2/lda2/ldw2 must be multiples of %d", epc);
+  const dim3 grid((a.N + 15) / 16, (a.M + 63) / 64), block(256);
+#define RG(T, NG, EPI, HX) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX>), grid, block, 0, st, a)
+  if (dtype == ST_BF16) {
+    if (epi == 0) RG(bf16_t, 1, 0, false);
+    else if (epi == 1) { if (has_x) RG(bf16_t, 3, 1, true); else RG(bf16_t, 3, 1, false); }
+    else { if (has_x) RG(bf16_t, 4, 2, true); else RG(bf16_t, 4, 2, false); }
+  } else {
+    if (epi == 0) RG(float, 1, 0, false);
+    else if (epi == 1) { if (has_x) RG(float, 3, 1, true); else RG(float, 3, 1, false); }
+    else { if (has_x) RG(float, 4, 2, true); else RG(float, 4, 2, false); }
+  }
+#undef RG
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline int grid1d(long work, int threads = 256) {
+  long b = (work + threads - 1) / threads;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int pack_inputs_launch(const void* feat, const void* emb, const long* cap, int Tcap, const int* rows_b, const int* rows_t,
+                       void* x0, long* target, int ntok, int E, int V, int mode, int dtype, hipStream_t st) {
+  if (ntok <= 0) return 0;
+  const int n = dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(E % n == 0, "pack_inputs: E=%d must be a multiple of %d", E, n);
+  const int grid = grid1d((long)ntok * (E / n));
+  if (dtype == ST_BF16) hipLaunchKernelGGL(pack_inputs_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)feat, (const bf16_t*)emb, cap, Tcap, rows_b, rows_t, (bf16_t*)x0, target, ntok, E, V, mode);
+  else hipLaunchKernelGGL(pack_inputs_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)feat, (const float*)emb, cap, Tcap, rows_b, rows_t, (float*)x0, target, ntok, E, V, mode);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+int embedding_bwd_launch(const float* dx0, const long* cap, int Tcap, const int* rows_b, const int* rows_t,
+                         float* dfeat, float* demb, int ntok, int E, int V, int mode, hipStream_t st) {
+  if (ntok <= 0) return 0;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid1d((long)ntok * E)), dim3(256), 0, st, dx0, cap, Tcap, rows_b, rows_t, dfeat, demb, ntok, E, V, mode);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+int gather_hprev_launch(const void* y, const int* rows_t, const int* prev_row, void* hp, int ntok, int H, int dtype, hipStream_t st) {
+  if (ntok <= 0) return 0;
+  const int n = dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(H % n == 0, "gather_hprev: H=%d must be a multiple of %d", H, n);
+  const int grid = grid1d((long)ntok * (H / n));
+  if (dtype == ST_BF16) hipLaunchKernelGGL(gather_hprev_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y, rows_t, prev_row, (bf16_t*)hp, ntok, H);
+  else hipLaunchKernelGGL(gather_hprev_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, rows_t, prev_row, (float*)hp, ntok, H);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+int gru_bwd_gates_launch(const float* dy, float* dhc, const void* cache, const void* hprev, void* dgx, void* dgh,
+                         int Bt, int H, int dtype, hipStream_t st) {
+  if (Bt <= 0) return 0;
+  const int grid = (Bt * (H / 4) + 255) / 256;
+  if (dtype == ST_BF16) hipLaunchKernelGGL(gru_bwd_gates_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, dy, dhc, (const bf16_t*)cache, (const bf16_t*)hprev, (bf16_t*)dgx, (bf16_t*)dgh, Bt, H);
+  else hipLaunchKernelGGL(gru_bwd_gates_kernel<float>, dim3(grid), dim3(256), 0, st, dy, dhc, (const float*)cache, (const float*)hprev, (float*)dgx, (float*)dgh, Bt, H);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+int lstm_bwd_gates_launch(const float* dy, float* dhc, float* dcc, const void* cache, const void* cnew, const void* cprev,
+                          void* dg, int Bt, int H, int dtype, hipStream_t st) {
+  if (Bt <= 0) return 0;
+  const int grid = (Bt * (H / 4) + 255) / 256;
+  if (dtype == ST_BF16) hipLaunchKernelGGL(lstm_bwd_gates_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, dy, dhc, dcc, (const bf16_t*)cache, (const bf16_t*)cnew, (const bf16_t*)cprev, (bf16_t*)dg, Bt, H);
+  else hipLaunchKernelGGL(lstm_bwd_gates_kernel<float>, dim3(grid), dim3(256), 0, st, dy, dhc, dcc, (const float*)cache, (const float*)cnew, (const float*)cprev, (float*)dg, Bt, H);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+int colsum_launch(const void* x, float* out, int rows, int cols, int ldx, int dtype, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const int rpb = 64;
+  const dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, out, rows, cols, ldx, rpb);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, rows, cols, ldx, rpb);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_cross_entropy(const void* logits, int logits_dtype, const long* target, int rows, int V, int ldl,
+                                float* loss_accum, void* dlogits, int dlogits_dtype, int ldd, float grad_scale,
+                                const float* grad_scale_dev, void* stream) {
+  ST_CHECK(logits && target, "st_cross_entropy: null pointer");
+  ST_CHECK(rows >= 0 && V > 0 && ldl >= V, "st_cross_entropy: bad shape");
+  if (rows == 0) return 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float inv = 1.0f / rows, gs = grad_scale / rows;
+  const dim3 grid(rows), block(256);
+  if (logits_dtype == ST_F32 && (dlogits_dtype == ST_F32 || !dlogits))
+    hipLaunchKernelGGL((ce_kernel<float, float>), grid, block, 0, st, (const float*)logits, target, loss_accum, (float*)dlogits, V, ldl, ldd, inv, gs, grad_scale_dev);
+  else if (logits_dtype == ST_F32)
+    hipLaunchKernelGGL((ce_kernel<float, bf16_t>), grid, block, 0, st, (const float*)logits, target, loss_accum, (bf16_t*)dlogits, V, ldl, ldd, inv, gs, grad_scale_dev);
+  else if (dlogits_dtype == ST_BF16 || !dlogits)
+    hipLaunchKernelGGL((ce_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)logits, target, loss_accum, (bf16_t*)dlogits, V, ldl, ldd, inv, gs, grad_scale_dev);
+  else
+    hipLaunchKernelGGL((ce_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)logits, target, loss_accum, (float*)dlogits, V, ldl, ldd, inv, gs, grad_scale_dev);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
