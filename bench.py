@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- training images/sec of the ResNet-101 + GRU captioner (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the reference training step (main.py:136-152) over one synthetic
+minibatch already resident in HBM: zero_grad, ResNet-101 forward in train mode (frozen, detached),
+Linear+BatchNorm1d head, 5-layer GRU over the packed captions, vocabulary projection + cross
+entropy, full backward, optimizer step.  Workload = BASELINE.json configs[1]: bf16, B=128/GPU,
+E=H=512, L=5, V=10000, SGD(lr=0.01, momentum=0.9) (main.py:48-51 defaults).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the MFMA implicit-GEMM
+convolution): algorithmic FLOPs of its launches / their summed duration, measured with HIP events
+on the launch stream in extra, separately instrumented steps right after the timed region (the
+timed steps themselves run uninstrumented).  `cpu_baseline` times the oracle's CPU restatement of
+the same step on the host cores (rank 0, N=1 only) on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+ENC_GFLOP_PER_IMG = 15.60           # 7.7994 GMAC of convolution per 224x224 image
+
+
+def cpu_baseline(threads, B=8, budget_s=12.0):
+    """Oracle (CPU restatement, fp32) of the same train step; returns images/sec on `threads` cores."""
+    from oracle import restatement as R
+    torch.set_num_threads(threads)
+    enc = R.init_encoder_params(101, 512, seed=1)
+    dec = {k: v.clone().requires_grad_(True) for k, v in R.init_decoder_params(512, 512, 10000, 5, "gru", seed=1).items()}
+    head = {k: enc[k].clone().requires_grad_(True) for k in ("linear_secondlast_layer.weight", "linear_secondlast_layer.bias",
+                                                             "last_layer.weight", "last_layer.bias")}
+    cap, lens = R.synthetic_captions(B, 10000, seed=1)
+    img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    bufs = {}
+
+    def step():
+        p = dict(enc); p.update(head)
+        feat = R.encoder_forward(p, img, 101, train=True)
+        loss, _, _ = R.gru_train_loss(dec, feat, cap, lens, "gru")
+        loss.backward()
+        with torch.no_grad():
+            for k, t in list(dec.items()) + list(head.items()):
+                bufs[k] = R.sgd_momentum_step(t, t.grad, bufs.get(k), 0.01, 0.9)
+                t.grad = None
+    step()  # warm-up (allocations, thread pool)
+    t0 = time.time()
+    steps = 0
+    while steps < 3 or time.time() - t0 < budget_s:
+        step()
+        steps += 1
+    dt = time.time() - t0
+    return B * steps / dt, dt, steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE: 128)")
+    ap.add_argument("--vocab", type=int, default=10000)
+    ap.add_argument("--optimizer", default="SGD", choices=["SGD", "Adam"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    a = ap.parse_args()
+
+    from showtell_amd import optim, parallel
+    from showtell_amd._lib import lib
+    from showtell_amd.cnn import ResNet
+    from showtell_amd.rnn import RNN
+    from showtell_amd.train import Trainer, synthetic_batch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    rank, world, local = parallel.init_from_env("nccl")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16
+    E, H, L, V, B = 512, 512, 5, a.vocab, a.batch
+
+    torch.manual_seed(1)                                     # main.py:26-27
+    cnn = ResNet(101, E, dtype=dtype).to(dev).train()        # main.py:92,125
+    rnn = RNN(E, H, V, L, dtype=dtype).to(dev).train()       # main.py:93,126
+    params = Trainer.trainable_params(cnn, rnn)              # main.py:96
+    opt = optim.SGD(params, lr=0.01, momentum=0.9) if a.optimizer == "SGD" else optim.Adam(params, lr=1e-4)
+    trainer = Trainer(cnn, rnn, opt, world)
+    image, caption, lens = synthetic_batch(B, V, seed=1 + rank, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(image, caption, lens)
+    trainer.flush()
+    barrier()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(a.steps):
+        loss = trainer.step(image, caption, lens)
+    trainer.flush()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item()) if loss is not None else float("nan")
+
+    # ---- roofline of the dominant kernel: instrumented steps, HIP events on the launch stream --------------
+    roof = None
+    if rank == 0:
+        lib().st_prof_enable(1)
+        for _ in range(max(1, a.profile_steps)):
+            trainer.step(image, caption, lens)
+        trainer.flush()
+        torch.cuda.synchronize()
+        ms, fl, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_long * 8)()
+        lib().st_prof_collect(ms, fl, n)
+        lib().st_prof_enable(0)
+        names = {0: "igemm_kernel<bf16,128,128,2,2>", 1: "igemm_kernel<bf16,128,64,4,1>", 2: "igemm_kernel<bf16,64,128,1,4>"}
+        v = max(range(8), key=lambda i: ms[i])
+        ach = fl[v] / (ms[v] * 1e-3) / 1e12 if ms[v] > 0 else 0.0
+        tot_ms, tot_fl = sum(ms), sum(fl)
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": names.get(v, f"variant{v}"), "launches": int(n[v]),
+                "avg_launch_us": round(ms[v] * 1e3 / max(1, n[v]), 2),
+                "all_igemm_TFLOPs": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
+                "all_igemm_ms_per_step": round(tot_ms / max(1, a.profile_steps), 3)}
+    if world > 1:
+        torch.distributed.barrier()
+
+    out = None
+    if rank == 0:
+        value = world * B * a.steps / dt
+        out = {"metric": "training images/sec (ResNet101+GRU, emb=512, bs=128) at 1/2/4/8 MI355X",
+               "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: ResNet-101 (train-mode BN, frozen) + 5-layer GRU decoder, "
+                                      "E=H=512, V=%d, fwd+bwd+%s step, synthetic COCO-shaped batch" % (V, a.optimizer),
+                          "batch_per_gpu": B, "global_batch": B * world, "image": "3x224x224",
+                          "tokens_per_batch": int(sum(lens)), "parallelism": "dp%d" % world,
+                          "final_loss": round(final_loss, 4)},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            cores = min(os.cpu_count() or 1, 16)
+            try:
+                v, secs, nst = cpu_baseline(cores)
+                out["cpu_baseline"] = {"value": round(v, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+                                       "sample": "oracle/restatement.py (torch CPU fp32) on the same train step at B=8: %d timed "
+                                                 "steps after 1 warm-up, %.1f s" % (nst, secs)}
+            except Exception as e:  # the baseline must never take the bench line down
+                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,9 +60,16 @@ typedef struct {
   int B, Hin, Win, Cin, Ho, Wo, N, KH, KW, stride, pad;
   int ldx, ldw, ldy;
   int relu, accumulate;
+  int Cin_logical;      /* 0 = Cin; the un-padded channel count (profiler FLOP accounting) */
 } st_conv_desc;
 
 int st_conv(const st_conv_desc* d, void* stream);
+
+/* Launch profiler for bench.py's roofline: HIP events around every st_conv launch on its stream.
+ * st_prof_collect fills 8-entry arrays indexed by kernel variant (0: bf16 128x128 tile,
+ * 1: bf16 128x64, 2: bf16 64x128, 4..6 the same for f32); synchronise the device first. */
+int st_prof_enable(int on);
+int st_prof_collect(double* ms, double* flops, long* launches);
 
 /* ------------------------------------------------------------------------------------
  * Batch-norm apply (+ residual)(+ ReLU), NHWC, fused elementwise pass.

@@ -19,7 +19,7 @@ class ConvDesc(C.Structure):
                 ("residual", c_p), ("stats", c_p), ("dtype", c_i), ("out_dtype", c_i),
                 ("B", c_i), ("Hin", c_i), ("Win", c_i), ("Cin", c_i), ("Ho", c_i), ("Wo", c_i), ("N", c_i),
                 ("KH", c_i), ("KW", c_i), ("stride", c_i), ("pad", c_i),
-                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i)]
+                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i), ("Cin_logical", c_i)]
 
 
 class BnActDesc(C.Structure):
@@ -51,6 +51,8 @@ class PackedSeq(C.Structure):
 _SIGS = {
     "st_version": ([], c_i),
     "st_conv": ([C.POINTER(ConvDesc), c_p], c_i),
+    "st_prof_enable": ([c_i], c_i),
+    "st_prof_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)], c_i),
     "st_bn_act": ([C.POINTER(BnActDesc), c_p], c_i),
     "st_bn_update_running": ([c_p, c_p, c_p, c_i, c_f, c_f, c_p], c_i),
     "st_nchw_to_nhwc": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
@@ -104,6 +106,9 @@ def lib():
             raise ShowTellHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the HIP path)")
+        # torch must load ITS HIP runtime first: the library then binds to the same libamdhip64 instance
+        # (loading /opt/rocm's copy before torch's leaves the process with two runtimes and no device).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.st_last_error.restype = C.c_char_p
         L.st_last_error.argtypes = []

@@ -24,7 +24,19 @@
 //     (pixel tile major), sharing the activation rows in that XCD's L2.
 #include "common.h"
 
+#include <vector>
+#include <mutex>
+
 namespace {
+
+// ---- optional launch profiler (bench.py roofline): HIP events around every igemm launch, on the
+// ---- launch stream.  Off by default; never touched on the normal path beyond one branch.
+constexpr int kVariants = 8;
+struct ProfRec { hipEvent_t e0, e1; int variant; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
+constexpr size_t kProfMax = 1 << 16;
 
 struct IgemmArgs {
   const void* x; const void* w; void* y;
@@ -34,6 +46,7 @@ struct IgemmArgs {
   int ldx, ldw, ldy;
   int relu, accumulate, out_f32;
   int nbm, nbn;
+  double flops;   // algorithmic 2*M*N*K (host side only, profiler)
 };
 
 template <typename T> struct Mfma;
@@ -295,6 +308,15 @@ int launch(IgemmArgs& a, hipStream_t st) {
   a.nbm = (a.M + BM - 1) / BM;
   a.nbn = (a.N + BN - 1) / BN;
   const int lds = 2 * (BM + BN) * 128;
+  constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + (BN == 64 ? 1 : (BM == 64 ? 2 : 0));
+  ProfRec rec; bool prof = false;
+  if (g_prof_on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.size() < kProfMax && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
+      rec.variant = variant; rec.flops = a.flops; prof = true;
+      (void)hipEventRecord(rec.e0, st);
+    }
+  }
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN>),
@@ -302,6 +324,11 @@ int launch(IgemmArgs& a, hipStream_t st) {
     attr_set = true;
   }
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
+  if (prof) {
+    (void)hipEventRecord(rec.e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(rec);
+  }
   ST_LAUNCH_CHECK();
   return 0;
 }
@@ -339,6 +366,29 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy;
   a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == ST_F32;
+  a.flops = 2.0 * a.M * a.N * d->KH * d->KW * (d->Cin_logical > 0 ? d->Cin_logical : d->Cin);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == ST_BF16 ? dispatch<bf16_t>(a, st) : dispatch<float>(a, st);
+}
+
+// ---- profiler control (used by bench.py only) -----------------------------------------------
+extern "C" int st_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+
+// Sums per kernel variant (0: bf16 128x128, 1: bf16 128x64, 2: bf16 64x128, 4..6: the f32 forms).
+// The caller must have synchronised the stream(s).  Arrays must hold 8 entries.
+extern "C" int st_prof_collect(double* ms, double* flops, long* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int v = 0; v < kVariants; ++v) { ms[v] = 0; flops[v] = 0; launches[v] = 0; }
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) { st_set_error("st_prof_collect: events not complete"); return 1; }
+    ms[r.variant] += t; flops[r.variant] += r.flops; launches[r.variant] += 1;
+  }
+  return 0;
 }

@@ -216,7 +216,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     d.B = B; d.Hin = hin; d.Win = win; d.Cin = cin_p;
     d.Ho = conv_out(hin, c.k, c.stride, c.pad); d.Wo = conv_out(win, c.k, c.stride, c.pad);
     d.N = c.cout; d.KH = c.k; d.KW = c.k; d.stride = c.stride; d.pad = c.pad;
-    d.ldx = cin_p; d.ldw = c.k * c.k * cin_p; d.ldy = c.cout;
+    d.ldx = cin_p; d.ldw = c.k * c.k * cin_p; d.ldy = c.cout; d.Cin_logical = c.cin;
     if (train) {
       d.stats = stats + 2 * c.bnoff;
     } else {

@@ -50,7 +50,7 @@ def conv_nhwc(x, w, KH, KW, stride, pad, out_dtype=None, bias=None, scale=None, 
     assert out.shape == (B, Ho, Wo, N) and out.dtype == out_dtype
     d = ConvDesc(_p(x), _p(w), _p(out), _p(bias), _p(scale), _p(shift), _p(residual), _p(stats),
                  dt_code(x), _DT[out_dtype], B, Hin, Win, Cin, Ho, Wo, N, KH, KW, stride, pad,
-                 Cin, w.shape[1], N, int(relu), int(accumulate))
+                 Cin, w.shape[1], N, int(relu), int(accumulate), 0)
     check(lib().st_conv(C.byref(d), _stream()), "st_conv")
     return out
 
@@ -70,7 +70,7 @@ def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=N
     ldy = out.stride(0)
     d = ConvDesc(_p(a), _p(w), _p(out), _p(bias), None, None, None, _p(stats),
                  dt_code(a), _DT[out.dtype], M, 1, 1, K, 1, 1, N, 1, 1, 1, 0,
-                 lda, ldw, ldy, int(relu), int(accumulate))
+                 lda, ldw, ldy, int(relu), int(accumulate), 0)
     check(lib().st_conv(C.byref(d), _stream()), "st_conv(gemm)")
     return out
 
