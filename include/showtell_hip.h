@@ -61,6 +61,7 @@ typedef struct {
   int ldx, ldw, ldy;
   int relu, accumulate;
   int Cin_logical;      /* 0 = Cin; the un-padded channel count (profiler FLOP accounting) */
+  int k_order;          /* 0: w is [N][KH][KW][Cin]; 1: w is [N][Cin/CH][KH][KW][CH], CH = 128 bytes of channels */
 } st_conv_desc;
 
 int st_conv(const st_conv_desc* d, void* stream);
@@ -68,6 +69,7 @@ int st_conv(const st_conv_desc* d, void* stream);
 /* Launch profiler for bench.py's roofline: HIP events around every st_conv launch on its stream.
  * st_prof_collect fills 8-entry arrays indexed by kernel variant (0: bf16 128x128 tile,
  * 1: bf16 128x64, 2: bf16 64x128, 4..6 the same for f32); synchronise the device first. */
+int st_tune(int ring, int kc, int w8);   /* main-loop variant knobs for tools/bench_conv.py; -1 = keep */
 int st_prof_enable(int on);
 int st_prof_collect(double* ms, double* flops, long* launches);
 
@@ -108,8 +110,9 @@ int st_global_avgpool(const void* x, void* y, int dtype, int out_dtype, int B, i
 int st_cast(const void* x, void* y, int from_dtype, int to_dtype, long n, void* stream);
 /* y[c][r] = x[r][c]; y has leading dimension ldy >= rows, pad columns zero-filled */
 int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx, int ldy, void* stream);
-/* conv weight repack: [Cout][Cin][KH][KW] fp32 (torch layout) -> [Cout][KH][KW][Cpad] dtype */
-int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, void* stream);
+/* conv weight repack: [Cout][Cin][KH][KW] fp32 (torch layout) -> [Cout][KH][KW][Cpad] dtype (k_order 0)
+ * or [Cout][Cpad/CH][KH][KW][CH] with CH = 64 (bf16) / 32 (f32) channels (k_order 1, see st_conv_desc) */
+int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, int k_order, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * ResNet-{18,34,50,101,152} backbone forward, one call (torchvision children()[:-1] /
@@ -131,7 +134,7 @@ int st_resnet_feat_dim(const st_resnet* r);
 size_t st_resnet_weight_elems(const st_resnet* r);
 size_t st_resnet_bn_channels(const st_resnet* r);
 int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cout, int* k, int* stride, int* pad,
-                        int* cin_padded, size_t* weight_offset, size_t* bn_offset);
+                        int* cin_padded, size_t* weight_offset, size_t* bn_offset, int* k_order);
 size_t st_resnet_workspace_bytes(const st_resnet* r, int B, int H, int W);
 int st_resnet_forward(const st_resnet* r, const float* images_nchw, int B, int H, int W,
                       const void* weights, const float* bn_gamma, const float* bn_beta,

@@ -19,7 +19,7 @@ class ConvDesc(C.Structure):
                 ("residual", c_p), ("stats", c_p), ("dtype", c_i), ("out_dtype", c_i),
                 ("B", c_i), ("Hin", c_i), ("Win", c_i), ("Cin", c_i), ("Ho", c_i), ("Wo", c_i), ("N", c_i),
                 ("KH", c_i), ("KW", c_i), ("stride", c_i), ("pad", c_i),
-                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i), ("Cin_logical", c_i)]
+                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i), ("Cin_logical", c_i), ("k_order", c_i)]
 
 
 class BnActDesc(C.Structure):
@@ -51,6 +51,7 @@ class PackedSeq(C.Structure):
 _SIGS = {
     "st_version": ([], c_i),
     "st_conv": ([C.POINTER(ConvDesc), c_p], c_i),
+    "st_tune": ([c_i, c_i, c_i], c_i),
     "st_prof_enable": ([c_i], c_i),
     "st_prof_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)], c_i),
     "st_bn_act": ([C.POINTER(BnActDesc), c_p], c_i),
@@ -61,7 +62,7 @@ _SIGS = {
     "st_global_avgpool": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_cast": ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
     "st_transpose": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
-    "st_pack_conv_weight": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_pack_conv_weight": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_cast2d": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_rnn_workspace_bytes": ([C.POINTER(RnnParams), C.POINTER(PackedSeq)], C.c_size_t),
     "st_rnn_forward": ([C.POINTER(RnnParams), C.POINTER(PackedSeq), c_p, c_p, c_p, C.c_size_t, c_p, c_i, c_i, c_p, c_i, c_p], c_i),
@@ -81,7 +82,7 @@ _SIGS = {
     "st_resnet_feat_dim": ([c_p], c_i),
     "st_resnet_weight_elems": ([c_p], C.c_size_t),
     "st_resnet_bn_channels": ([c_p], C.c_size_t),
-    "st_resnet_conv_info": ([c_p, c_i] + [C.POINTER(c_i)] * 6 + [C.POINTER(C.c_size_t)] * 2, c_i),
+    "st_resnet_conv_info": ([c_p, c_i] + [C.POINTER(c_i)] * 6 + [C.POINTER(C.c_size_t)] * 2 + [C.POINTER(c_i)], c_i),
     "st_resnet_workspace_bytes": ([c_p, c_i, c_i, c_i], C.c_size_t),
     "st_resnet_forward": ([c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, C.c_size_t,
                            c_p, c_p, c_i, c_p, c_p], c_i),

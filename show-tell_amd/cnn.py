@@ -118,9 +118,10 @@ class _Backbone:
             for i in range(n):
                 v = [C.c_int() for _ in range(6)]
                 o = [C.c_size_t(), C.c_size_t()]
-                check(lib().st_resnet_conv_info(h, i, *[C.byref(a) for a in v], *[C.byref(a) for a in o]), "conv_info")
+                ko = C.c_int()
+                check(lib().st_resnet_conv_info(h, i, *[C.byref(a) for a in v], *[C.byref(a) for a in o], C.byref(ko)), "conv_info")
                 self.info.append(dict(cin=v[0].value, cout=v[1].value, k=v[2].value, stride=v[3].value, pad=v[4].value,
-                                      cin_p=v[5].value, woff=o[0].value, bnoff=o[1].value))
+                                      cin_p=v[5].value, woff=o[0].value, bnoff=o[1].value, korder=ko.value))
                 conv = self.pairs[i][0]
                 assert tuple(conv.weight.shape) == (v[1].value, v[0].value, v[2].value, v[2].value)
         return self.handle
@@ -163,7 +164,7 @@ class _Backbone:
             w = conv.weight.data
             assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
             check(lib().st_pack_conv_weight(C.c_void_p(w.data_ptr()), C.c_void_p(self.packed.data_ptr() + inf["woff"] * es),
-                                            dt, inf["cout"], inf["cin"], inf["k"], inf["k"], inf["cin_p"], st),
+                                            dt, inf["cout"], inf["cin"], inf["k"], inf["k"], inf["cin_p"], inf["korder"], st),
                   "st_pack_conv_weight")
         self.packed_key = key
 

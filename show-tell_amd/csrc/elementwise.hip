@@ -234,14 +234,25 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out,
-                                                                int Cout, int Cin, int KH, int KW, int Cpad) {
+                                                                int Cout, int Cin, int KH, int KW, int Cpad, int CH) {
   const long total = (long)Cout * KH * KW * Cpad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Cpad);
-    long t = i / Cpad;
-    const int kw = (int)(t % KW); t /= KW;
-    const int kh = (int)(t % KH);
-    const long co = t / KH;
+    int c, kw, kh; long co;
+    if (CH == 0) {            // [Cout][KH][KW][Cpad]
+      c = (int)(i % Cpad);
+      long t = i / Cpad;
+      kw = (int)(t % KW); t /= KW;
+      kh = (int)(t % KH);
+      co = t / KH;
+    } else {                  // [Cout][Cpad/CH][KH][KW][CH]
+      const int cl = (int)(i % CH);
+      long t = i / CH;
+      kw = (int)(t % KW); t /= KW;
+      kh = (int)(t % KH); t /= KH;
+      const int cc = (int)(t % (Cpad / CH));
+      co = t / (Cpad / CH);
+      c = cc * CH + cl;
+    }
     out[i] = from_f32<T>(c < Cin ? w[((co * Cin + c) * KH + kh) * KW + kw] : 0.f);
   }
 }
@@ -377,15 +388,17 @@ extern "C" int st_transpose(const void* x, void* y, int dtype, int rows, int col
   return 0;
 }
 
-extern "C" int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, void* stream) {
+extern "C" int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, int k_order, void* stream) {
   ST_CHECK(w && out, "st_pack_conv_weight: null pointer");
   ST_DT_CHECK(dtype, "st_pack_conv_weight");
   ST_CHECK(Cpad >= Cin, "st_pack_conv_weight: Cpad < Cin");
+  const int CH = k_order ? (dtype == ST_BF16 ? 64 : 32) : 0;
+  ST_CHECK(!k_order || Cpad % CH == 0, "st_pack_conv_weight: k_order=1 needs Cpad %% %d == 0", CH);
   const long total = (long)Cout * KH * KW * Cpad;
   const int grid = grid_for(total, 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ST_BF16) hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin, KH, KW, Cpad);
-  else hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)out, Cout, Cin, KH, KW, Cpad);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin, KH, KW, Cpad, CH);
+  else hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)out, Cout, Cin, KH, KW, Cpad, CH);
   ST_LAUNCH_CHECK();
   return 0;
 }

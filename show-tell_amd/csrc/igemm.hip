@@ -26,6 +26,7 @@
 
 #include <vector>
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 
@@ -44,7 +45,7 @@ struct IgemmArgs {
   int M, N, K;
   int Hin, Win, Cin, Ho, Wo, KH, KW, stride, pad;
   int ldx, ldw, ldy;
-  int relu, accumulate, out_f32;
+  int relu, accumulate, out_f32, korder;
   int nbm, nbn;
   double flops;   // algorithmic 2*M*N*K (host side only, profiler)
 };
@@ -64,135 +65,16 @@ template <> struct Mfma<float> {
   }
 };
 
+// ---- epilogue shared by both main loops ---------------------------------------------------------
+// On entry every wave has passed a barrier after its last LDS read of the K loop and no LDS-DMA is in flight.
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
+                                               int bm, int bn, int tid) {
   constexpr int NT = 64 * WM * WN;
-  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
-  constexpr int BK = 8 * EPC;                // K elements per tile row (128 bytes)
-  constexpr int RPP = NT / 8;                // rows covered per loader pass
-  constexpr int PA = BM / RPP, PB = BN / RPP;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
-  constexpr int TILE_BYTES = (BM + BN) * 128;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  // ---- XCD-aware tile assignment (bijective for any grid size) -------------------
-  const int nblk = a.nbm * a.nbn;
-  int lid;
-  {
-    const int id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-  }
-  const int bm = lid / a.nbn, bn = lid - bm * a.nbn;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid - wm * WN;
-
-  // ---- loader state ----------------------------------------------------------------
-  const int ccol = tid & 7, lrow = tid >> 3;
-  int pixbase[PA], hw0[PA];
-  const int HoWo = a.Ho * a.Wo;
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int m = bm * BM + lrow + i * RPP;
-    if (m < a.M) {
-      const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
-      pixbase[i] = b * a.Hin * a.Win;
-      const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
-      hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
-    } else {
-      pixbase[i] = 0;
-      hw0[i] = (int)0x80008000;  // hi0 = wi0 = -32768: never in range
-    }
-  }
-  long wrow[PB];
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int n = bn * BN + lrow + i * RPP;
-    wrow[i] = n < a.N ? (long)n * a.ldw : -1;
-  }
-  // running (kh, kw, c) of this thread's chunk column
-  int kc = ccol * EPC, kh = 0, kw = 0;
-  while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
-  int klin = ccol * EPC;
-
-  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
-
-  u32x4 ra[PA], rb[PB];
-  auto gload = [&]() {
-    const bool kok = kh < a.KH;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int hi = (hw0[i] >> 16) + kh, wi = (int)(short)(hw0[i] & 0xffff) + kw;
-      const bool ok = kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const u32x4*>(X + ((long)(pixbase[i] + hi * a.Win + wi) * a.ldx + kc));
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (kok && wrow[i] >= 0) v = *reinterpret_cast<const u32x4*>(W + (wrow[i] + klin));
-      rb[i] = v;
-    }
-    // advance to the next K tile
-    klin += BK;
-    kc += BK;
-    while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
-  };
-  auto lstore = [&](int buf) {
-    char* base = smem + buf * TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int row = lrow + i * RPP;
-      *reinterpret_cast<u32x4*>(base + row * 128 + ((ccol ^ (row & 7)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int row = lrow + i * RPP;
-      *reinterpret_cast<u32x4*>(base + (BM + row) * 128 + ((ccol ^ (row & 7)) << 4)) = rb[i];
-    }
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int r16 = lane & 15, q4 = lane >> 4;
-  const int nk = (a.K + BK - 1) / BK;
-
-  gload();
-  lstore(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) gload();
-    const char* base = smem + (kt & 1) * TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int swz = ((ks * 4 + q4) ^ (r16 & 7)) << 4;
-      u32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const u32x4*>(base + (wm * (BM / WM) + i * 16 + r16) * 128 + swz);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const u32x4*>(base + (BM + wn * (BN / WN) + j * 16 + r16) * 128 + swz);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
-    }
-    if (more) lstore((kt + 1) & 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue ------------------------------------------------------------------------
   // lane holds, for tile (i,j): pixel m = m0 + i*16 + r16, channels n = n0 + j*16 + 4*q4 + e
   const int m0 = bm * BM + wm * (BM / WM), n0 = bn * BN + wn * (BN / WN);
 
@@ -236,36 +118,65 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
     }
   }
 
+  // ---- staged store: registers -> LDS (fp32, 64-row halves) -> 16-byte coalesced global stores --------
+  // Every output row leaves as whole 128-byte lines (8 consecutive channels per lane, 16 lanes per row).
+  constexpr int SROW = BN + 4;                       // floats per staged row (+16 B: spreads the banks)
+  float* stage = reinterpret_cast<float*>(smem);     // [64][SROW] <= 33.8 KB, K-loop buffers are dead
+  constexpr int HALVES = BM / 64;
+  const int my_half = (wm * (BM / WM)) / 64;
+  const int lrow0 = (wm * (BM / WM)) % 64;           // this wave's first row inside its half
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + i * 16 + r16;
-    if (m >= a.M) continue;
+  for (int h = 0; h < HALVES; ++h) {
+    __syncthreads();                                  // stats reduction / previous half has left the buffer
+    if (my_half == h) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + j * 16 + 4 * q4;
-      if (n >= a.N) continue;
-      float v[4];
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-      const bool full = n + 3 < a.N;
-      const long off = (long)m * a.ldy + n;
+        for (int j = 0; j < TN; ++j) {
+          const int nl = wn * (BN / WN) + j * 16 + 4 * q4;
+          const int n = bn * BN + nl;
+          f32x4 v = acc[i][j];
+          if (a.bias || a.scale) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (full || n + e < a.N) {
-          if (a.bias) v[e] += a.bias[n + e];
-          if (a.scale) v[e] = v[e] * a.scale[n + e] + a.shift[n + e];
+            for (int e = 0; e < 4; ++e) {
+              if (n + e < a.N) {
+                if (a.bias) v[e] += a.bias[n + e];
+                if (a.scale) v[e] = v[e] * a.scale[n + e] + a.shift[n + e];
+              }
+            }
+          }
+          *reinterpret_cast<f32x4*>(stage + (lrow0 + i * 16 + r16) * SROW + nl) = v;
         }
-      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                       // 8-channel chunks per row
+    constexpr int RPI = NT / CPR;                     // rows per pass
+    const int c8 = (tid % CPR) * 8, rr = tid / CPR;
+    const int n = bn * BN + c8;
+#pragma unroll
+    for (int r = rr; r < 64; r += RPI) {
+      const int m = bm * BM + h * 64 + r;
+      if (m >= a.M || n >= a.N) continue;
+      float v[8];
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * SROW + c8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * SROW + c8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+      const long off = (long)m * a.ldy + n;
+      const bool full = (n + 7 < a.N) && ((a.ldy & 7) == 0);
       if (a.out_f32) {
         float* Y = reinterpret_cast<float*>(a.y) + off;
         const float* R = a.residual ? reinterpret_cast<const float*>(a.residual) + off : nullptr;
         if (full) {
-          if (R) { const f32x4 r = *reinterpret_cast<const f32x4*>(R); for (int e = 0; e < 4; ++e) v[e] += r[e]; }
-          if (a.relu) for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          if (a.accumulate) { const f32x4 o = *reinterpret_cast<const f32x4*>(Y); for (int e = 0; e < 4; ++e) v[e] += o[e]; }
+          if (R) { const f32x4 r0 = *reinterpret_cast<const f32x4*>(R), r1 = *reinterpret_cast<const f32x4*>(R + 4);
+                   for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; } }
+          if (a.relu) for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          if (a.accumulate) { const f32x4 o0 = *reinterpret_cast<const f32x4*>(Y), o1 = *reinterpret_cast<const f32x4*>(Y + 4);
+                              for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; } }
           *reinterpret_cast<f32x4*>(Y) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(Y + 4) = f32x4{v[4], v[5], v[6], v[7]};
         } else {
-          for (int e = 0; e < 4 && n + e < a.N; ++e) {
+          for (int e = 0; e < 8 && n + e < a.N; ++e) {
             float t = v[e];
             if (R) t += R[e];
             if (a.relu) t = fmaxf(t, 0.f);
@@ -278,19 +189,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
         const uint16_t* R = a.residual ? reinterpret_cast<const uint16_t*>(a.residual) + off : nullptr;
         if (full) {
           if (R) {
-            const u32x2 r = *reinterpret_cast<const u32x2*>(R);
-            v[0] += __uint_as_float(r[0] << 16); v[1] += __uint_as_float(r[0] & 0xffff0000u);
-            v[2] += __uint_as_float(r[1] << 16); v[3] += __uint_as_float(r[1] & 0xffff0000u);
+            const u32x4 r4 = *reinterpret_cast<const u32x4*>(R);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
           }
-          if (a.relu) for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          if (a.relu) for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
           if (a.accumulate) {
-            const u32x2 o = *reinterpret_cast<const u32x2*>(Y);
-            v[0] += __uint_as_float(o[0] << 16); v[1] += __uint_as_float(o[0] & 0xffff0000u);
-            v[2] += __uint_as_float(o[1] << 16); v[3] += __uint_as_float(o[1] & 0xffff0000u);
+            const u32x4 o4 = *reinterpret_cast<const u32x4*>(Y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(o4[e] << 16); v[2 * e + 1] += __uint_as_float(o4[e] & 0xffff0000u); }
           }
-          *reinterpret_cast<u32x2*>(Y) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x4*>(Y) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         } else {
-          for (int e = 0; e < 4 && n + e < a.N; ++e) {
+          for (int e = 0; e < 8 && n + e < a.N; ++e) {
             float t = v[e];
             if (R) t += bf16_bits_to_f32(R[e]);
             if (a.relu) t = fmaxf(t, 0.f);
@@ -303,12 +214,344 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch(IgemmArgs& a, hipStream_t st) {
+// chunk slot of (row, chunk) inside a tile row of KC 16-byte chunks; both make the ds_read_b128 of an
+// MFMA operand (16 rows x 4 chunks, lane groups of MI355X_MICROARCH 'LDS') bank-conflict free
+template <int KC> __device__ __forceinline__ int swz(int row, int c) {
+  return KC == 8 ? (c ^ (row & 7)) : (c ^ ((-(row >> 2)) & 3));
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool FAST>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int BK = KC * EPC;               // K elements per tile row (KC chunks = 128 or 64 bytes)
+  constexpr int ROWB = KC * 16;
+  constexpr int RPP = NT / KC;               // rows covered per loader pass
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
+  constexpr int TILE_BYTES = (BM + BN) * ROWB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- XCD-aware tile assignment (bijective for any grid size) -------------------
+  const int nblk = a.nbm * a.nbn;
+  int lid;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int bm = lid / a.nbn, bn = lid - bm * a.nbn;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid - wm * WN;
+
+  // ---- loader state ----------------------------------------------------------------
+  // FAST (Cin % BK == 0): every chunk of a K tile lies in ONE filter tap, so the tap walk is block-uniform
+  // (scalar registers); a row keeps a base pointer and a bit mask of its in-bounds taps, and a chunk costs
+  // one bit test + one pointer add.  Otherwise (the 7x7 stem, Cin = 8) each thread walks (kh, kw, c) itself.
+  const int ccol = tid % KC, lrow = tid / KC;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
+  int pixbase[PA], hw0[PA];
+  const T* arow[PA];
+  unsigned long long amask[PA];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = bm * BM + lrow + i * RPP;
+    pixbase[i] = 0; hw0[i] = (int)0x80008000; arow[i] = X; amask[i] = 0ull;   // hi0 = wi0 = -32768: never in range
+    if (m < a.M) {
+      const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+      pixbase[i] = b * a.Hin * a.Win;
+      hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
+      if (FAST) {
+        arow[i] = X + ((long)(pixbase[i] + hi0 * a.Win + wi0) * a.ldx + ccol * EPC);
+        for (int fh = 0; fh < a.KH; ++fh)
+          for (int fw = 0; fw < a.KW; ++fw)
+            if ((unsigned)(hi0 + fh) < (unsigned)a.Hin && (unsigned)(wi0 + fw) < (unsigned)a.Win)
+              amask[i] |= 1ull << (fh * a.KW + fw);
+      }
+    }
+  }
+  const T* wptr[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int n = bn * BN + lrow + i * RPP;
+    wptr[i] = n < a.N ? W + ((long)n * a.ldw + ccol * EPC) : nullptr;
+  }
+  // walk state: FAST -> block-uniform (tap, c0, tapoff); generic -> this thread's (kh, kw, kc)
+  int kc = FAST ? 0 : ccol * EPC, kh = 0, kw = 0, tap = 0;
+  long tapoff = 0;
+  if (!FAST) while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+  int klin = 0;
+  const int ntap = a.KH * a.KW;
+
+  u32x4 ra[PA], rb[PB];
+  auto gload = [&]() {
+    const bool kok = FAST ? (a.korder ? kc < a.Cin : tap < ntap) : kh < a.KH;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (FAST) {
+        if (kok && ((amask[i] >> tap) & 1ull)) v = *reinterpret_cast<const u32x4*>(arow[i] + (tapoff + kc));
+      } else {
+        const int hi = (hw0[i] >> 16) + kh, wi = (int)(short)(hw0[i] & 0xffff) + kw;
+        if (kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win)
+          v = *reinterpret_cast<const u32x4*>(X + ((long)(pixbase[i] + hi * a.Win + wi) * a.ldx + kc));
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kok && wptr[i]) v = *reinterpret_cast<const u32x4*>(wptr[i] + klin);
+      rb[i] = v;
+    }
+    // advance to the next K tile
+    klin += BK;
+    kc += BK;
+    if (FAST) {
+      if (a.korder) {   // channel chunk outer, filter tap inner: the taps of one chunk re-touch the same lines (L1)
+        kc -= BK;
+        ++tap; if (++kw == a.KW) { kw = 0; ++kh; }
+        if (tap == ntap) { tap = 0; kh = 0; kw = 0; kc += BK; }
+        tapoff = (long)(kh * a.Win + kw) * a.ldx;
+      } else if (kc >= a.Cin) { kc = 0; ++tap; if (++kw == a.KW) { kw = 0; ++kh; } tapoff = (long)(kh * a.Win + kw) * a.ldx; }
+    } else {
+      while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int row = lrow + i * RPP;
+      *reinterpret_cast<u32x4*>(base + row * ROWB + (swz<KC>(row, ccol) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int row = lrow + i * RPP;
+      *reinterpret_cast<u32x4*>(base + (BM + row) * ROWB + (swz<KC>(row, ccol) << 4)) = rb[i];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int nk = (a.K + BK - 1) / BK;
+
+  gload();
+  lstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) gload();
+    const char* base = smem + (kt & 1) * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int so = swz<KC>(r16, ks * 4 + q4) << 4;
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const u32x4*>(base + (wm * (BM / WM) + i * 16 + r16) * ROWB + so);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const u32x4*>(base + (BM + wn * (BN / WN) + j * 16 + r16) * ROWB + so);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+    }
+    if (more) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
+}
+
+// =======================================================================================
+// Main loop 2: LDS-DMA ring.  global_load_lds (16 B per lane, 1 KiB per wave-instruction) writes the
+// K-tiles straight into a ring of NS LDS stages, NS-1 tiles ahead of the MFMAs; a tile is waited for
+// with a COUNTED s_waitcnt vmcnt (never 0 inside the loop) and one raw s_barrier per K-tile.
+// The LDS image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE chunk and to the
+// reads (cdna_hip_programming.md rule 21).  Padding / ragged lanes read a 16-byte zero word instead.
+// One 4-wave block per CU (NS x 32 KiB of LDS): latency is hidden by the ring, not by occupancy.
+// =======================================================================================
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool FAST>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_ring_kernel(IgemmArgs a) {
+  constexpr int NT = 64 * WM * WN, NW = WM * WN;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);     // 1-KiB pieces (8 rows) per wave per tile
+  constexpr int G = PA + PB;                                // LDS-DMA instructions per wave per tile
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int TILE_BYTES = (BM + BN) * 128;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/loader mismatch");
+  static_assert((NS - 1) * G <= 63, "vmcnt range");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = a.nbm * a.nbn;
+  int lid;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int bm = lid / a.nbn, bn = lid - bm * a.nbn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid - wm * WN;
+
+  // lane -> (row inside an 8-row piece, source chunk); LDS slot lane&7 of that row receives chunk ccol
+  const int prow = lane >> 3, ccol = (lane & 7) ^ prow;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
+  const T* Z = reinterpret_cast<const T*>(g_zero16);
+  int pixbase[PA], hw0[PA];
+  const T* arow[PA];
+  unsigned long long amask[PA];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = bm * BM + (wid + NW * i) * 8 + prow;
+    pixbase[i] = 0; hw0[i] = (int)0x80008000; arow[i] = X; amask[i] = 0ull;
+    if (m < a.M) {
+      const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+      pixbase[i] = b * a.Hin * a.Win;
+      hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
+      if (FAST) {
+        arow[i] = X + ((long)(pixbase[i] + hi0 * a.Win + wi0) * a.ldx + ccol * EPC);
+        for (int fh = 0; fh < a.KH; ++fh)
+          for (int fw = 0; fw < a.KW; ++fw)
+            if ((unsigned)(hi0 + fh) < (unsigned)a.Hin && (unsigned)(wi0 + fw) < (unsigned)a.Win)
+              amask[i] |= 1ull << (fh * a.KW + fw);
+      }
+    }
+  }
+  const T* wptr[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int n = bn * BN + (wid + NW * i) * 8 + prow;
+    wptr[i] = n < a.N ? W + ((long)n * a.ldw + ccol * EPC) : nullptr;
+  }
+  int kc = FAST ? 0 : ccol * EPC, kh = 0, kw = 0, tap = 0;
+  long tapoff = 0;
+  if (!FAST) while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+  int klin = 0;
+  const int ntap = a.KH * a.KW;
+
+  auto issue = [&](int stage) {
+    char* base = smem + stage * TILE_BYTES;
+    const bool kok = FAST ? (a.korder ? kc < a.Cin : tap < ntap) : kh < a.KH;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const T* src = Z;
+      if (FAST) {
+        const T* cand = arow[i] + (tapoff + kc);
+        src = (kok && ((amask[i] >> tap) & 1ull)) ? cand : Z;
+      } else {
+        const int hi = (hw0[i] >> 16) + kh, wi = (int)(short)(hw0[i] & 0xffff) + kw;
+        const bool ok = kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+        src = ok ? X + ((long)(pixbase[i] + hi * a.Win + wi) * a.ldx + kc) : Z;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (wid + NW * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const T* src = (kok && wptr[i]) ? wptr[i] + klin : Z;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + BM * 128 + (wid + NW * i) * 1024), 16, 0, 0);
+    }
+    klin += BK;
+    kc += BK;
+    if (FAST) {
+      if (a.korder) {   // channel chunk outer, filter tap inner: the taps of one chunk re-touch the same lines (L1)
+        kc -= BK;
+        ++tap; if (++kw == a.KW) { kw = 0; ++kh; }
+        if (tap == ntap) { tap = 0; kh = 0; kw = 0; kc += BK; }
+        tapoff = (long)(kh * a.Win + kw) * a.ldx;
+      } else if (kc >= a.Cin) { kc = 0; ++tap; if (++kw == a.KW) { kw = 0; ++kh; } tapoff = (long)(kh * a.Win + kw) * a.ldx; }
+    } else {
+      while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int nk = (a.K + BK - 1) / BK;
+
+  // Software pipeline (per wave): the fragment reads of the NEXT half K-tile are in flight while the MFMAs of
+  // the current half run, so the LDS phase and the matrix phase of a wave overlap instead of alternating:
+  //   reads f1(kt) | MFMA f0(kt) | wait tile kt+1 + barrier | DMA tile kt+NS | reads f0(kt+1) | MFMA f1(kt)
+  // Tiles past the end of K are all-zero reads: they keep the DMA counts uniform.
+  auto read_frags = [&](const char* base, int ks, u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
+    const int so = ((ks * 4 + q4) ^ (r16 & 7)) << 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      fa[i] = *reinterpret_cast<const u32x4*>(base + (wm * (BM / WM) + i * 16 + r16) * 128 + so);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      fb[j] = *reinterpret_cast<const u32x4*>(base + (BM + wn * (BN / WN) + j * 16 + r16) * 128 + so);
+  };
+  auto mma = [&](u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+  };
+
+#pragma unroll
+  for (int s = 0; s < NS; ++s) issue(s);
+  wait_vmcnt<(NS - 1) * G>();                      // tile 0 has landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();                    // ... and everybody else's
+  u32x4 fa0[TM] = {}, fb0[TN] = {}, fa1[TM] = {}, fb1[TN] = {};
+  read_frags(smem, 0, fa0, fb0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = smem + (kt % NS) * TILE_BYTES;
+    const char* nxt = smem + ((kt + 1) % NS) * TILE_BYTES;
+    read_frags(cur, 1, fa1, fb1);
+    mma(fa0, fb0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // f1(kt) is in registers: this wave is done with tile kt
+    wait_vmcnt<(NS - 2) * G>();                    // tile kt+1 has landed
+    __builtin_amdgcn_s_barrier();                  // everybody is done with tile kt; tile kt+1 is complete
+    issue(kt % NS);                                // refill the stage just released with tile kt+NS
+    read_frags(nxt, 0, fa0, fb0);
+    mma(fa1, fb1);
+  }
+  wait_vmcnt<0>();                                 // the over-issued (all-zero) tail tiles
+  __syncthreads();
+  igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool FAST>
+int launch_(IgemmArgs& a, hipStream_t st) {
   a.nbm = (a.M + BM - 1) / BM;
   a.nbn = (a.N + BN - 1) / BN;
-  const int lds = 2 * (BM + BN) * 128;
-  constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + (BN == 64 ? 1 : (BM == 64 ? 2 : 0));
+  constexpr int kloop = 2 * (BM + BN) * KC * 16, stage = 64 * (BN + 4) * 4;
+  const int lds = kloop > stage ? kloop : stage;
+  constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + (BN == 64 ? 1 : (BM == 64 ? 2 : (BM == 256 ? 3 : 0)));
   ProfRec rec; bool prof = false;
   if (g_prof_on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -319,11 +562,11 @@ int launch(IgemmArgs& a, hipStream_t st) {
   }
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, KC, FAST>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, FAST>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
   if (prof) {
     (void)hipEventRecord(rec.e1, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -333,15 +576,83 @@ int launch(IgemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <typename T>
-int dispatch(IgemmArgs& a, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN, int KC>
+int launch(IgemmArgs& a, hipStream_t st) {
+  constexpr int BK = KC * (16 / (int)sizeof(T));
+  const bool fast = (a.Cin % BK == 0) && a.KH * a.KW <= 64;
+  return fast ? launch_<T, BM, BN, WM, WN, KC, true>(a, st) : launch_<T, BM, BN, WM, WN, KC, false>(a, st);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool FAST>
+int launch_ring_(IgemmArgs& a, hipStream_t st) {
+  a.nbm = (a.M + BM - 1) / BM;
+  a.nbn = (a.N + BN - 1) / BN;
+  constexpr int lds = NS * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<T, BM, BN, WM, WN, NS, FAST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + 3;
+  ProfRec rec; bool prof = false;
+  if (g_prof_on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.size() < kProfMax && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
+      rec.variant = variant; rec.flops = a.flops; prof = true;
+      (void)hipEventRecord(rec.e0, st);
+    }
+  }
+  hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BN, WM, WN, NS, FAST>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
+  if (prof) {
+    (void)hipEventRecord(rec.e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(rec);
+  }
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+int launch_ring(IgemmArgs& a, hipStream_t st) {
+  constexpr int BK = 8 * (16 / (int)sizeof(T));
+  const bool fast = (a.Cin % BK == 0) && a.KH * a.KW <= 64;
+  return fast ? launch_ring_<T, BM, BN, WM, WN, NS, true>(a, st) : launch_ring_<T, BM, BN, WM, WN, NS, false>(a, st);
+}
+
+int g_tune[3] = {-1, -1, -1};   // ring, kc, w8 (-1: take the environment default)
+int tuning_get(int i, const char* env) {
+  if (g_tune[i] < 0) { const char* e = getenv(env); g_tune[i] = e ? atoi(e) : 0; }
+  return g_tune[i];
+}
+int tuning_ring() { return tuning_get(0, "ST_IGEMM_RING"); }
+
+int tuning_w8() { if (g_tune[2] < 0) { const char* e = getenv("ST_IGEMM_W8"); g_tune[2] = e ? atoi(e) : 1; } return g_tune[2]; }
+int tuning_kc() { return tuning_get(1, "ST_IGEMM_KC"); }
+
+template <typename T, int KC>
+int dispatch_kc(IgemmArgs& a, hipStream_t st) {
   // Tile choice: fill >= ~1.5 waves of the 256 CUs where the problem allows it.
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (a.N <= 64) return launch<T, 128, 64, 4, 1>(a, st);
-  if (t128 >= 384) return launch<T, 128, 128, 2, 2>(a, st);
+  if (a.N <= 64) return launch<T, 128, 64, 4, 1, KC>(a, st);
+  if (tuning_w8() == 2 && a.M >= 256 * 64) return launch<T, 256, 128, 4, 2, KC>(a, st);
+  if (t128 >= 384) return tuning_w8() ? launch<T, 128, 128, 2, 4, KC>(a, st) : launch<T, 128, 128, 2, 2, KC>(a, st);
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
-  if (t64 >= 256 || a.M <= 64) return launch<T, 64, 128, 1, 4>(a, st);
-  return launch<T, 128, 128, 2, 2>(a, st);
+  if (t64 >= 256 || a.M <= 64) return launch<T, 64, 128, 1, 4, KC>(a, st);
+  return tuning_w8() ? launch<T, 128, 128, 2, 4, KC>(a, st) : launch<T, 128, 128, 2, 2, KC>(a, st);
+}
+
+template <typename T>
+int dispatch(IgemmArgs& a, hipStream_t st) {
+  const int ring = tuning_ring();
+  if (ring == 3 && a.N > 64) return launch_ring<T, 128, 128, 2, 2, 3>(a, st);
+  if (ring == 4 && a.N > 64) return launch_ring<T, 128, 128, 2, 2, 4>(a, st);
+  if (ring == 13 && a.N > 64) return launch_ring<T, 128, 128, 2, 4, 3>(a, st);
+  if (ring == 14 && a.N > 64) return launch_ring<T, 128, 128, 2, 4, 4>(a, st);
+  if (ring == 23 && a.N > 64) return launch_ring<T, 256, 128, 4, 2, 3>(a, st);
+  const int kc = tuning_kc();
+  if (kc == 4 && !a.korder) return dispatch_kc<T, 4>(a, st);
+  return dispatch_kc<T, 8>(a, st);
 }
 
 }  // namespace
@@ -358,6 +669,7 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   ST_CHECK(d->Hin < 32768 && d->Win < 32768, "st_conv: spatial size too large");
   ST_CHECK((long)d->B * d->Hin * d->Win * d->ldx < (1L << 40), "st_conv: input too large");
   ST_CHECK((d->scale == nullptr) == (d->shift == nullptr), "st_conv: scale and shift must be given together");
+  ST_CHECK(!d->k_order || (d->Cin % (8 * epc) == 0 && d->KH * d->KW <= 64), "st_conv: k_order=1 needs Cin to be a multiple of %d", 8 * epc);
   IgemmArgs a;
   a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.scale = d->scale; a.shift = d->shift;
   a.residual = d->residual; a.stats = d->stats;
@@ -366,9 +678,18 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy;
   a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == ST_F32;
+  a.korder = d->k_order;
   a.flops = 2.0 * a.M * a.N * d->KH * d->KW * (d->Cin_logical > 0 ? d->Cin_logical : d->Cin);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == ST_BF16 ? dispatch<bf16_t>(a, st) : dispatch<float>(a, st);
+}
+
+// Benchmarking knob (tools/bench_conv.py): main-loop variant selection; -1 keeps the current value.
+extern "C" int st_tune(int ring, int kc, int w8) {
+  if (ring >= 0) g_tune[0] = ring;
+  if (kc >= 0) g_tune[1] = kc;
+  if (w8 >= 0) g_tune[2] = w8;
+  return 0;
 }
 
 // ---- profiler control (used by bench.py only) -----------------------------------------------

@@ -17,7 +17,7 @@
 #include <new>
 #include <string.h>
 
-struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; };
+struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; int korder; };
 struct BlockL { int c1, c2, c3, ds; int stride; };  // indices into convs (c3 = -1 for basic blocks, ds = -1 if none)
 
 struct st_resnet {
@@ -86,7 +86,8 @@ extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
   const int epc = dtype == ST_BF16 ? 8 : 4;
   r->cpad0 = epc;  // 3 input channels zero-padded to one 16-byte chunk
   auto add = [&](int cin, int cout, int k, int s, int p) {
-    ConvL c{cin, cout, k, s, p, r->wtotal, r->bntotal};
+    const int ch = dtype == ST_BF16 ? 64 : 32;
+    ConvL c{cin, cout, k, s, p, r->wtotal, r->bntotal, (k > 1 && cin % ch == 0) ? 1 : 0};
     const int cin_p = (cin == 3) ? r->cpad0 : cin;
     r->wtotal += (size_t)cout * k * k * cin_p;
     r->bntotal += cout;
@@ -126,7 +127,7 @@ extern "C" size_t st_resnet_weight_elems(const st_resnet* r) { return r ? r->wto
 extern "C" size_t st_resnet_bn_channels(const st_resnet* r) { return r ? r->bntotal : 0; }
 
 extern "C" int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cout, int* k, int* stride, int* pad,
-                                   int* cin_padded, size_t* weight_offset, size_t* bn_offset) {
+                                   int* cin_padded, size_t* weight_offset, size_t* bn_offset, int* k_order) {
   ST_CHECK(r && i >= 0 && i < (int)r->convs.size(), "st_resnet_conv_info: bad index %d", i);
   const ConvL& c = r->convs[i];
   if (cin) *cin = c.cin;
@@ -137,6 +138,7 @@ extern "C" int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cou
   if (cin_padded) *cin_padded = c.cin == 3 ? r->cpad0 : c.cin;
   if (weight_offset) *weight_offset = c.woff;
   if (bn_offset) *bn_offset = c.bnoff;
+  if (k_order) *k_order = c.korder;
   return 0;
 }
 
@@ -216,7 +218,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     d.B = B; d.Hin = hin; d.Win = win; d.Cin = cin_p;
     d.Ho = conv_out(hin, c.k, c.stride, c.pad); d.Wo = conv_out(win, c.k, c.stride, c.pad);
     d.N = c.cout; d.KH = c.k; d.KW = c.k; d.stride = c.stride; d.pad = c.pad;
-    d.ldx = cin_p; d.ldw = c.k * c.k * cin_p; d.ldy = c.cout; d.Cin_logical = c.cin;
+    d.ldx = cin_p; d.ldw = c.k * c.k * cin_p; d.ldy = c.cout; d.Cin_logical = c.cin; d.k_order = c.korder;
     if (train) {
       d.stats = stats + 2 * c.bnoff;
     } else {

@@ -36,7 +36,7 @@ def _dev(*ts):
 
 
 def conv_nhwc(x, w, KH, KW, stride, pad, out_dtype=None, bias=None, scale=None, shift=None,
-              residual=None, stats=None, relu=False, out=None, accumulate=False):
+              residual=None, stats=None, relu=False, out=None, accumulate=False, k_order=0):
     """x: (B,Hin,Win,Cin) NHWC; w: (N, KH*KW*Cin) K-contiguous.  Returns (B,Ho,Wo,N)."""
     _dev(x, w, bias, scale, shift, residual, stats, out)
     B, Hin, Win, Cin = x.shape
@@ -50,7 +50,7 @@ def conv_nhwc(x, w, KH, KW, stride, pad, out_dtype=None, bias=None, scale=None, 
     assert out.shape == (B, Ho, Wo, N) and out.dtype == out_dtype
     d = ConvDesc(_p(x), _p(w), _p(out), _p(bias), _p(scale), _p(shift), _p(residual), _p(stats),
                  dt_code(x), _DT[out_dtype], B, Hin, Win, Cin, Ho, Wo, N, KH, KW, stride, pad,
-                 Cin, w.shape[1], N, int(relu), int(accumulate), 0)
+                 Cin, w.shape[1], N, int(relu), int(accumulate), 0, int(k_order))
     check(lib().st_conv(C.byref(d), _stream()), "st_conv")
     return out
 
@@ -70,7 +70,7 @@ def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=N
     ldy = out.stride(0)
     d = ConvDesc(_p(a), _p(w), _p(out), _p(bias), None, None, None, _p(stats),
                  dt_code(a), _DT[out.dtype], M, 1, 1, K, 1, 1, N, 1, 1, 1, 0,
-                 lda, ldw, ldy, int(relu), int(accumulate), 0)
+                 lda, ldw, ldy, int(relu), int(accumulate), 0, 0)
     check(lib().st_conv(C.byref(d), _stream()), "st_conv(gemm)")
     return out
 
@@ -153,11 +153,11 @@ def transpose(x, ldy=None, out=None):
     return out
 
 
-def pack_conv_weight(w, dtype, cpad=None):
-    """(Cout,Cin,KH,KW) fp32 torch layout -> (Cout, KH*KW*Cpad) K-contiguous."""
+def pack_conv_weight(w, dtype, cpad=None, k_order=0):
+    """(Cout,Cin,KH,KW) fp32 torch layout -> (Cout, KH*KW*Cpad) K-contiguous (k_order: see st_conv_desc)."""
     _dev(w)
     Cout, Cin, KH, KW = w.shape
     cpad = cpad or Cin
     out = torch.empty(Cout, KH * KW * cpad, device=w.device, dtype=dtype)
-    check(lib().st_pack_conv_weight(_p(w), _p(out), _DT[dtype], Cout, Cin, KH, KW, cpad, _stream()), "st_pack_conv_weight")
+    check(lib().st_pack_conv_weight(_p(w), _p(out), _DT[dtype], Cout, Cin, KH, KW, cpad, int(k_order), _stream()), "st_pack_conv_weight")
     return out

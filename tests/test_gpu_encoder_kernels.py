@@ -39,11 +39,14 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("k_order", [0, 1])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_matches_conv2d(case, dtype):
+def test_conv_matches_conv2d(case, dtype, k_order):
     ops = _ops()
     B, H, W, Cin, Cout, k, s, p = case
+    if k_order and (k == 1 or Cin % 64):
+        pytest.skip("channel-chunk-major K order applies to k>1 convs with Cin % 64 == 0")
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
@@ -51,9 +54,9 @@ def test_conv_matches_conv2d(case, dtype):
         x, w = x.bfloat16().float(), w.bfloat16().float()
     ref = F.conv2d(x, w, None, s, p).permute(0, 2, 3, 1).contiguous()
     xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", dtype)
-    wd = ops.pack_conv_weight(w.cuda(), dtype)
+    wd = ops.pack_conv_weight(w.cuda(), dtype, k_order=k_order)
     stats = torch.zeros(2 * Cout, device="cuda")
-    y = ops.conv_nhwc(xd, wd, k, k, s, p, stats=stats)
+    y = ops.conv_nhwc(xd, wd, k, k, s, p, stats=stats, k_order=k_order)
     torch.cuda.synchronize()
     _close(y, ref, dtype, "conv")
     # batch-norm statistics from the epilogue (fp32 accumulators, before output rounding)
