@@ -224,6 +224,19 @@ size_t st_rnn_greedy_workspace_bytes(const st_rnn_params* p, int B);
 int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, int steps, void* workspace, size_t workspace_bytes,
                   long* ids_out, float* logits_out, void* stream);
 
+/* Building blocks of the beam decoders (rnn.py:60-108 and beam_search.py:45-97):
+ * st_rnn_step: one timestep of the L-layer cell for n independent rows, states [L][n][H] in `dtype`
+ *   (h_in/c_in NULL = zero state, as nn.GRU(x, None)), optional fp32 logits [n][ldl] = linear(h_top);
+ * st_embedding_rows: x[r] = embeddings[ids[r]] (rnn.py:53,85);
+ * st_gather_state: dst[l][r] = src[l][idx[r]] (a child beam inherits its parent's recurrent state);
+ * st_softmax_topk: per row the k largest entries in DESCENDING order with their indices; values are
+ *   softmax probabilities (beam_search.py:83-88) or, with raw != 0, the raw logits (rnn.py:90-91). */
+int st_rnn_step(const st_rnn_params* p, const void* x, int n, const void* h_in, const void* c_in,
+                void* h_out, void* c_out, float* logits, int ldl, void* stream);
+int st_embedding_rows(const void* emb, const long* ids, void* out, int n, int E, int V, int ldo, int dtype, void* stream);
+int st_gather_state(const void* src, const int* idx, void* dst, int L, int n_src, int n_dst, int H, int dtype, void* stream);
+int st_softmax_topk(const float* logits, int ldl, int n, int V, int k, float* top_p, long* top_id, int raw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,10 @@ _SIGS = {
                          c_p, c_p, c_p], c_i),
     "st_rnn_greedy_workspace_bytes": ([C.POINTER(RnnParams), c_i], C.c_size_t),
     "st_rnn_greedy": ([C.POINTER(RnnParams), c_p, c_i, c_i, c_p, C.c_size_t, c_p, c_p, c_p], c_i),
+    "st_rnn_step": ([C.POINTER(RnnParams), c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p], c_i),
+    "st_embedding_rows": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_gather_state": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_softmax_topk": ([c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p], c_i),
     "st_cross_entropy": ([c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_p], c_i),
     "st_head_workspace_bytes": ([c_i, c_i, c_i, c_i], C.c_size_t),
     "st_linear_bn1d_forward": ([c_p] * 7 + [c_i, c_i, c_i, c_i, c_i, c_f, c_f] + [c_p] * 6, c_i),

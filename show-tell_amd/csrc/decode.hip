@@ -46,6 +46,85 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
   }
 }
 
+
+// x[r] = emb[ids[r]]  (rows of E elements, 16 bytes per lane)
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_rows_kernel(const T* __restrict__ emb, const long* __restrict__ ids, T* __restrict__ out,
+                                                             int n, int E, int V, int ldo) {
+  constexpr int N = 16 / (int)sizeof(T);
+  const int cpr = E / N;
+  const long total = (long)n * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cpr), c = (int)(i - (long)r * cpr) * N;
+    long t = ids[r]; t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    *reinterpret_cast<u32x4*>(out + (long)r * ldo + c) = *reinterpret_cast<const u32x4*>(emb + t * E + c);
+  }
+}
+
+// dst[l][r] = src[l][idx[r]]  (beam bookkeeping: children inherit their parent's state)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_state_kernel(const T* __restrict__ src, const int* __restrict__ idx, T* __restrict__ dst,
+                                                           int L, int n_src, int n_dst, int H) {
+  constexpr int N = 16 / (int)sizeof(T);
+  const int cpr = H / N;
+  const long total = (long)L * n_dst * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpr) * N;
+    long t = i / cpr;
+    const int r = (int)(t % n_dst), l = (int)(t / n_dst);
+    int s = idx[r]; s = s < 0 ? 0 : (s >= n_src ? n_src - 1 : s);
+    *reinterpret_cast<u32x4*>(dst + ((long)l * n_dst + r) * H + c) = *reinterpret_cast<const u32x4*>(src + ((long)l * n_src + s) * H + c);
+  }
+}
+
+// Per row: softmax probabilities (fp32) of the k largest logits, in DESCENDING order, with their indices.
+// raw != 0: rank and return the raw logits instead (rnn.py:90-91 uses topk on result_state directly).
+__global__ __launch_bounds__(256) void softmax_topk_kernel(const float* __restrict__ logits, int ldl, int V, int k,
+                                                           float* __restrict__ top_p, long* __restrict__ top_id, int raw) {
+  __shared__ float sv[4]; __shared__ int si[4]; __shared__ float ssum[4];
+  __shared__ int chosen[32];
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float* l = logits + (long)row * ldl;
+  float M = -INFINITY;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) M = fmaxf(M, l[i]);
+  M = wave_max(M);
+  if (lane == 0) sv[wid] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+  float S = 0.f;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) S += expf(l[i] - M);
+  S = wave_sum(S);
+  if (lane == 0) ssum[wid] = S;
+  __syncthreads();
+  S = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+  for (int j = 0; j < k; ++j) {
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+      bool used = false;
+      for (int q = 0; q < j; ++q) used |= (chosen[q] == i);
+      const float v = l[i];
+      if (!used && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    best = sv[0]; bi = si[0];
+    for (int w = 1; w < 4; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    if (bi >= V) bi = 0;
+    if (threadIdx.x == 0) {
+      chosen[j] = bi;
+      top_id[(long)row * k + j] = bi;
+      top_p[(long)row * k + j] = raw ? best : expf(best - M) / S;
+    }
+    __syncthreads();
+  }
+}
+
 int gemm_nt(const void* a, int lda, const void* w, int ldw, void* y, int ldy, int M, int N, int K, int dtype, int out_dtype,
             const float* bias, void* stream) {
   st_conv_desc d;
@@ -111,6 +190,78 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
     ST_LAUNCH_CHECK();
     x = xbuf;
     cur = nxt;
+  }
+  return 0;
+}
+
+extern "C" int st_embedding_rows(const void* emb, const long* ids, void* out, int n, int E, int V, int ldo, int dtype, void* stream) {
+  ST_CHECK(emb && ids && out, "st_embedding_rows: null pointer");
+  const int nn = dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(E % nn == 0 && ldo % nn == 0 && ldo >= E, "st_embedding_rows: E=%d / ldo=%d must be multiples of %d", E, ldo, nn);
+  if (n <= 0) return 0;
+  long b = ((long)n * (E / nn) + 255) / 256; if (b > 2048) b = 2048;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(embedding_rows_kernel<bf16_t>, dim3((int)b), dim3(256), 0, st, (const bf16_t*)emb, ids, (bf16_t*)out, n, E, V, ldo);
+  else hipLaunchKernelGGL(embedding_rows_kernel<float>, dim3((int)b), dim3(256), 0, st, (const float*)emb, ids, (float*)out, n, E, V, ldo);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_gather_state(const void* src, const int* idx, void* dst, int L, int n_src, int n_dst, int H, int dtype, void* stream) {
+  ST_CHECK(src && idx && dst, "st_gather_state: null pointer");
+  const int nn = dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(H % nn == 0, "st_gather_state: H=%d must be a multiple of %d", H, nn);
+  if (n_dst <= 0) return 0;
+  long b = ((long)L * n_dst * (H / nn) + 255) / 256; if (b > 2048) b = 2048;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(gather_state_kernel<bf16_t>, dim3((int)b), dim3(256), 0, st, (const bf16_t*)src, idx, (bf16_t*)dst, L, n_src, n_dst, H);
+  else hipLaunchKernelGGL(gather_state_kernel<float>, dim3((int)b), dim3(256), 0, st, (const float*)src, idx, (float*)dst, L, n_src, n_dst, H);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_softmax_topk(const float* logits, int ldl, int n, int V, int k, float* top_p, long* top_id, int raw, void* stream) {
+  ST_CHECK(logits && top_p && top_id, "st_softmax_topk: null pointer");
+  ST_CHECK(k >= 1 && k <= 32 && k <= V && ldl >= V, "st_softmax_topk: need 1 <= k <= min(32, V)");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(softmax_topk_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+// One timestep of the multi-layer cell for n independent rows (+ optional vocabulary projection).
+extern "C" int st_rnn_step(const st_rnn_params* p, const void* x, int n, const void* h_in, const void* c_in,
+                           void* h_out, void* c_out, float* logits, int ldl, void* stream) {
+  ST_CHECK(p && x && h_out, "st_rnn_step: null pointer");
+  ST_CHECK(p->L >= 1 && p->L <= ST_MAX_LAYERS, "st_rnn_step: bad layer count");
+  ST_CHECK(p->H % 8 == 0 && p->in0 % 8 == 0, "st_rnn_step: in0=%d and H=%d must be multiples of 8", p->in0, p->H);
+  ST_CHECK(p->cell == ST_CELL_GRU || c_out, "st_rnn_step: LSTM needs c_out");
+  ST_CHECK(h_in != h_out, "st_rnn_step: h_in and h_out must not alias");
+  if (n <= 0) return 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int dt = p->dtype, H = p->H;
+  const size_t es = st_dtype_size(dt);
+  for (int l = 0; l < p->L; ++l) {
+    RnnGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = n; a.N = H; a.gstride = H;
+    a.A2 = l == 0 ? x : reinterpret_cast<const char*>(h_out) + (size_t)(l - 1) * n * H * es;
+    a.W2 = p->w_ih[l]; a.K2 = l == 0 ? p->in0 : H; a.lda2 = a.K2; a.ldw2 = a.K2;
+    a.A = h_in ? reinterpret_cast<const char*>(h_in) + (size_t)l * n * H * es : nullptr;
+    a.W = p->w_hh[l]; a.K = H; a.lda = H; a.ldw = H;
+    a.hprev = a.A; a.ldhp = H;
+    a.bias_h = p->b_hh[l]; a.bias_x = p->b_ih[l];
+    a.hout = reinterpret_cast<char*>(h_out) + (size_t)l * n * H * es; a.ldho = H;
+    if (p->cell == ST_CELL_LSTM) {
+      a.cprev = c_in ? reinterpret_cast<const char*>(c_in) + (size_t)l * n * H * es : nullptr;
+      a.cout = reinterpret_cast<char*>(c_out) + (size_t)l * n * H * es;
+    }
+    if (rnn_gemm_launch(a, dt, p->cell == ST_CELL_GRU ? 1 : 2, 1, st)) return 1;
+  }
+  if (logits) {
+    ST_CHECK(p->w_lin && p->b_lin && ldl % 4 == 0 && ldl >= p->V, "st_rnn_step: bad logits buffer");
+    if (gemm_nt(reinterpret_cast<const char*>(h_out) + (size_t)(p->L - 1) * n * H * es, H, p->w_lin, H, logits, ldl, n, p->V, H, dt, ST_F32,
+                p->b_lin, stream)) return 1;
   }
   return 0;
 }

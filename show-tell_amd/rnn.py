@@ -189,6 +189,11 @@ class RNN(torch.nn.Module):
         """main.py:145-149 fused: CrossEntropyLoss()(rnn(feat, cap, lens), packed(cap)) as one scalar."""
         return _DecoderFn.apply(cnn_feature, self.linear.bias, self, image_caption, caption_size, "loss", torch.is_grad_enabled())
 
+    def beam_search(self, cnn_feature, beam_width=4, num_hypotheses=1, max_length=50, start_id=1, end_id=2):
+        """beam_search.py:45-97 over the whole batch (BASELINE config 5: beam_width=5, max_length=25)."""
+        from .beam import beam_search
+        return beam_search(self, cnn_feature, beam_width, num_hypotheses, max_length, start_id, end_id)
+
     def sentence_index(self, cnn_feature, beam_size=0, return_logits=False):
         """rnn.py:37-108: 25-step greedy decode (beam_size=0) or the bs=1 ranking loop (beam_size>0)."""
         if beam_size and beam_size > 0:

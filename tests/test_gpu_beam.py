@@ -1,0 +1,63 @@
+"""GPU parity of the two beam decoders against vectors produced by the reference itself
+(rnn.py:60-108 via RNN.sentence_index(beam_size=k); beam_search.py driven by the reference's RNN)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+from tests._util import load_fixture
+from tests.test_gpu_decoder import _make
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", [1, 3, 5])
+def test_quirky_beam_ids_exact_vs_reference(k):
+    params, _, d = load_fixture("gru_small.npz")
+    m = _make("gru", params, torch.float32).eval()
+    feat = torch.from_numpy(d["feat"])[:1].cuda()
+    ids = m.sentence_index(feat, beam_size=k)
+    assert ids.shape == (25,) and ids.dtype == torch.int64
+    assert np.array_equal(ids.cpu().numpy(), d[f"qbeam{k}"])
+    with pytest.raises(ValueError):
+        m.sentence_index(torch.from_numpy(d["feat"])[:2].cuda(), beam_size=k)   # bs=1 only (rnn.py:60)
+
+
+@pytest.mark.parametrize("bw,nh", [(5, 3), (4, 1)])
+def test_beam_search_sequences_exact_vs_reference(bw, nh):
+    params, _, d = load_fixture("beam_small.npz")
+    m = _make("gru", params, torch.float32).eval()
+    feat = torch.from_numpy(d["feat"]).cuda()
+    out = m.beam_search(feat, beam_width=bw, num_hypotheses=nh, max_length=int(d[f"bw{bw}_maxlen"]))
+    assert len(out) == feat.shape[0]
+    for b, hyp in enumerate(out):
+        lens = d[f"bw{bw}_len"][b]
+        assert len(hyp) == int((lens > 0).sum())            # [] when nothing completed (beam_search.py:69-79)
+        for i, (seq, cost) in enumerate(hyp):
+            assert seq == d[f"bw{bw}_seq"][b, i, :lens[i]].tolist()
+            assert abs(cost - d[f"bw{bw}_cost"][b, i]) < 1e-3
+
+
+def test_beam_search_full_size_matches_oracle_and_is_batch_invariant():
+    """E=H=512, L=5, V=10000 (BASELINE config 5 shape, fewer images): ids equal the oracle's, and an image's
+    result does not depend on what else is in the batch."""
+    E, H, V, L, B = 512, 512, 10000, 5, 12
+    params = R.init_decoder_params(E, H, V, L, "gru", seed=6)
+    params["linear.weight"] = params["linear.weight"] * 12.0      # sharpen so that <end> competes (see gen_golden.gen_beam)
+    params["linear.bias"][2] += 1.5
+    m = _make("gru", params, torch.float32).eval()
+    feat = torch.randn(B, E, generator=torch.Generator().manual_seed(6))
+    got = m.beam_search(feat.cuda(), beam_width=5, num_hypotheses=1, max_length=25)
+    nonempty = 0
+    for b in range(B):
+        with torch.no_grad():
+            init, gen = R.gru_beam_callbacks(params, feat[b])
+            hyp = R.beam_search(init, gen, [0], 1, 2, beam_width=5, num_hypotheses=1, max_length=25)
+        assert len(got[b]) == len(hyp)
+        if hyp:
+            nonempty += 1
+            assert got[b][0][0] == hyp[0].to_sequence_of_values()
+            assert got[b][0][0][0] == 1 and got[b][0][0][-1] == 2
+    assert nonempty >= 3
+    sub = m.beam_search(feat[3:7].cuda(), beam_width=5, num_hypotheses=1, max_length=25)
+    assert [h[0][0] if h else None for h in sub] == [h[0][0] if h else None for h in got[3:7]]
