@@ -237,6 +237,47 @@ int st_embedding_rows(const void* emb, const long* ids, void* out, int n, int E,
 int st_gather_state(const void* src, const int* idx, void* dst, int L, int n_src, int n_dst, int H, int dtype, void* stream);
 int st_softmax_topk(const float* logits, int ldl, int n, int V, int k, float* top_p, long* top_id, int raw, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Soft-attention decoder (Attention/rnn_attn.py, rnn_attn_LSTM.py; train step Attention/main_attn.py:123-134).
+ *   features: cnn_feature (B,F,P) fp32 as cnn_attn.py:49 returns it; caption_T: int64 [Tcap][B] (transposed captions).
+ *   Per step t (rnn_attn.py:66-74): attention over P pixels keyed on the last layer's h, x = [emb(cap[:,t]) ; embed(z)],
+ *   one step of the L-layer cell on the first B_t rows, logits rows written time-major packed (rnn_attn.py:115).
+ *   alphas (B,T,P) fp32 must be zero-filled by the caller (the reference zero-pads, rnn_attn.py:65).
+ *   The time-invariant encoder_att projection is computed once per batch instead of once per step.
+ * st_attn_backward accumulates (+=) every parameter gradient, including the doubly-stochastic term
+ *   alpha_c * mean((1 - sum_t alpha)^2) (main_attn.py:131) scaled like the loss (grad_scale_dev, optional).
+ * st_attn_reg_loss adds that term to *loss_accum.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  st_rnn_params rnn;                               /* rnn.in0 = 2E */
+  int F, A, P;
+  const void* w_enc; const float* b_enc;           /* attn.encoder_att [A][F] dtype, [A] */
+  const void* w_dec; const float* b_dec;           /* attn.decoder_att [A][H] dtype, [A] */
+  const float* w_full; const float* b_full;        /* attn.full_att    [A] fp32, [1]     */
+  const void* w_init_h; const float* b_init_h;     /* init_h [H][F] dtype                */
+  const void* w_init_c; const float* b_init_c;     /* init_c (LSTM only)                 */
+  const void* w_embed; const float* b_embed;       /* embed [E][F] dtype                 */
+} st_attn_params;
+
+typedef struct {
+  st_rnn_grads rnn;
+  float *w_enc, *b_enc, *w_dec, *b_dec, *w_full, *b_full, *w_init_h, *b_init_h, *w_init_c, *b_init_c, *w_embed, *b_embed;
+} st_attn_grads;
+
+size_t st_attn_workspace_bytes(const st_attn_params* p, const st_packed_seq* s);
+int st_attn_forward(const st_attn_params* p, const st_packed_seq* s, const float* cnn_feature, const long* caption_T,
+                    void* workspace, size_t workspace_bytes, void* logits, int logits_dtype, int ldl,
+                    float* alphas, int save_for_backward, void* stream);
+int st_attn_backward(const st_attn_params* p, const st_attn_grads* g, const st_packed_seq* s, const long* caption_T,
+                     const void* dlogits, int ldd, const float* alphas,
+                     const float* dalphas /* (B,T,P) gradient w.r.t. alphas from the caller, or NULL: use alpha_c */,
+                     float alpha_c, const float* grad_scale_dev, void* workspace, size_t workspace_bytes, void* stream);
+int st_attn_reg_loss(const float* alphas, int B, int T, int P, float alpha_c, float* loss_accum, void* stream);
+/* rnn_attn.py:120-145 (test branch 77-94): `steps` greedy iterations from <start>; ids_out[B][steps] int64 */
+size_t st_attn_greedy_workspace_bytes(const st_attn_params* p, int B);
+int st_attn_greedy(const st_attn_params* p, const float* cnn_feature, int B, int steps, long start_id,
+                   void* workspace, size_t workspace_bytes, long* ids_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

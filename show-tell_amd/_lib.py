@@ -43,6 +43,17 @@ class RnnGrads(C.Structure):
                 ("b_ih", c_p * ST_MAX_LAYERS), ("b_hh", c_p * ST_MAX_LAYERS), ("w_lin", c_p), ("b_lin", c_p)]
 
 
+class AttnParams(C.Structure):
+    _fields_ = [("rnn", RnnParams), ("F", c_i), ("A", c_i), ("P", c_i),
+                ("w_enc", c_p), ("b_enc", c_p), ("w_dec", c_p), ("b_dec", c_p), ("w_full", c_p), ("b_full", c_p),
+                ("w_init_h", c_p), ("b_init_h", c_p), ("w_init_c", c_p), ("b_init_c", c_p), ("w_embed", c_p), ("b_embed", c_p)]
+
+
+class AttnGrads(C.Structure):
+    _fields_ = [("rnn", RnnGrads)] + [(n, c_p) for n in ("w_enc", "b_enc", "w_dec", "b_dec", "w_full", "b_full", "w_init_h", "b_init_h",
+                                                        "w_init_c", "b_init_c", "w_embed", "b_embed")]
+
+
 class PackedSeq(C.Structure):
     _fields_ = [("B", c_i), ("T", c_i), ("ntok", c_i), ("Tcap", c_i), ("batch_sizes_host", C.POINTER(c_i)),
                 ("rows_b", c_p), ("rows_t", c_p), ("prev_row", c_p), ("caption", c_p)]
@@ -74,6 +85,12 @@ _SIGS = {
     "st_embedding_rows": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_gather_state": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_softmax_topk": ([c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p], c_i),
+    "st_attn_workspace_bytes": ([c_p, c_p], C.c_size_t),
+    "st_attn_forward": ([c_p, c_p, c_p, c_p, c_p, C.c_size_t, c_p, c_i, c_i, c_p, c_i, c_p], c_i),
+    "st_attn_backward": ([c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_p, C.c_size_t, c_p], c_i),
+    "st_attn_reg_loss": ([c_p, c_i, c_i, c_i, c_f, c_p, c_p], c_i),
+    "st_attn_greedy_workspace_bytes": ([c_p, c_i], C.c_size_t),
+    "st_attn_greedy": ([c_p, c_p, c_i, c_i, c_l, c_p, C.c_size_t, c_p, c_p], c_i),
     "st_cross_entropy": ([c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_p], c_i),
     "st_head_workspace_bytes": ([c_i, c_i, c_i, c_i], C.c_size_t),
     "st_linear_bn1d_forward": ([c_p] * 7 + [c_i, c_i, c_i, c_i, c_i, c_f, c_f] + [c_p] * 6, c_i),

@@ -379,7 +379,7 @@ extern "C" int st_cast2d(const void* x, void* y, int from_dtype, int to_dtype, i
 extern "C" int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx, int ldy, void* stream) {
   ST_CHECK(x && y, "st_transpose: null pointer");
   ST_DT_CHECK(dtype, "st_transpose");
-  ST_CHECK(ldx >= cols && ldy >= rows, "st_transpose: leading dimensions too small");
+  ST_CHECK(ldx >= cols && ldy >= rows, "st_transpose: leading dimensions too small (rows=%d cols=%d ldx=%d ldy=%d)", rows, cols, ldx, ldy);
   const dim3 grid((cols + 63) / 64, (ldy + 63) / 64);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == ST_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, cols, ldx, ldy);

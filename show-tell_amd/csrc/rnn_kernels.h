@@ -22,7 +22,8 @@ int pack_inputs_launch(const void* feat, const void* emb, const long* cap, int T
                        void* x0, long* target, int ntok, int E, int V, int mode, int dtype, hipStream_t st);
 int embedding_bwd_launch(const float* dx0, const long* cap, int Tcap, const int* rows_b, const int* rows_t,
                          float* dfeat, float* demb, int ntok, int E, int V, int mode, hipStream_t st);
-int gather_hprev_launch(const void* y, const int* rows_t, const int* prev_row, void* hp, int ntok, int H, int dtype, hipStream_t st);
+int gather_hprev_launch(const void* y, const int* rows_t, const int* prev_row, void* hp, int ntok, int H, int dtype, hipStream_t st,
+                        const void* h0 = nullptr, const int* rows_b = nullptr);
 int gru_bwd_gates_launch(const float* dy, float* dhc, const void* cache, const void* hprev, void* dgx, void* dgh,
                          int Bt, int H, int dtype, hipStream_t st);
 int lstm_bwd_gates_launch(const float* dy, float* dhc, float* dcc, const void* cache, const void* cnew, const void* cprev,

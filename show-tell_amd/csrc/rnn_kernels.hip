@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
 // hprev[row(t,b)] = t == 0 ? h0 : y[row(t-1,b)]   (operand of dW_hh = sum_t dgh_t^T h_{t-1})
 template <typename T>
 __global__ __launch_bounds__(256) void gather_hprev_kernel(const T* __restrict__ y, const int* __restrict__ rows_t,
-                                                           const int* __restrict__ prev_row, T* __restrict__ hp, int ntok, int H) {
+                                                           const int* __restrict__ prev_row, T* __restrict__ hp, int ntok, int H,
+                                                           const T* __restrict__ h0, const int* __restrict__ rows_b) {
   constexpr int N = 16 / (int)sizeof(T);
   const int cpr = H / N;
   const long total = (long)ntok * cpr;
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void gather_hprev_kernel(const T* __restrict__
     const int row = (int)(i / cpr), c = (int)(i - (long)row * cpr) * N;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (rows_t[row] > 0) v = *reinterpret_cast<const u32x4*>(y + (long)prev_row[row] * H + c);
+    else if (h0) v = *reinterpret_cast<const u32x4*>(h0 + (long)rows_b[row] * H + c);
     *reinterpret_cast<u32x4*>(hp + (long)row * H + c) = v;
   }
 }
@@ -422,13 +424,14 @@ int embedding_bwd_launch(const float* dx0, const long* cap, int Tcap, const int*
   return 0;
 }
 
-int gather_hprev_launch(const void* y, const int* rows_t, const int* prev_row, void* hp, int ntok, int H, int dtype, hipStream_t st) {
+int gather_hprev_launch(const void* y, const int* rows_t, const int* prev_row, void* hp, int ntok, int H, int dtype, hipStream_t st,
+                        const void* h0, const int* rows_b) {
   if (ntok <= 0) return 0;
   const int n = dtype == ST_BF16 ? 8 : 4;
   ST_CHECK(H % n == 0, "gather_hprev: H=%d must be a multiple of %d", H, n);
   const int grid = grid1d((long)ntok * (H / n));
-  if (dtype == ST_BF16) hipLaunchKernelGGL(gather_hprev_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y, rows_t, prev_row, (bf16_t*)hp, ntok, H);
-  else hipLaunchKernelGGL(gather_hprev_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, rows_t, prev_row, (float*)hp, ntok, H);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(gather_hprev_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y, rows_t, prev_row, (bf16_t*)hp, ntok, H, (const bf16_t*)h0, rows_b);
+  else hipLaunchKernelGGL(gather_hprev_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, rows_t, prev_row, (float*)hp, ntok, H, (const float*)h0, rows_b);
   ST_LAUNCH_CHECK();
   return 0;
 }
