@@ -9,7 +9,7 @@
 //   main.py:149    nn.CrossEntropyLoss (fwd + bwd)               -> ce_kernel
 //
 // The recurrent product h_{t-1} W_hh^T has only B_t <= batch rows, so it is launch/latency
-// bound, not FLOP bound: one block owns 16 hidden units (all gates of those units) x 64 batch
+// bound, not FLOP bound: one block owns 16 hidden units (all gates of those units) x 32 batch
 // rows, operands go straight from L2 to MFMA fragments (no LDS: each fragment is used once),
 // and the whole gate nonlinearity runs in the epilogue so a timestep is ONE launch.
 #include "common.h"
@@ -70,19 +70,27 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0,
     const T* W = reinterpret_cast<const T*>(Wp) + (long)n * ldw;
     const long gs = (long)a.gstride * ldw;
     const int nsteps = (K + 4 * EPC - 1) / (4 * EPC);
-    for (int s = 0; s < nsteps; ++s) {
-      const int k = (s * 4 + q4) * EPC;
-      const bool kok = k < K;
-      u32x4 fa = {0u, 0u, 0u, 0u};
-      if (mok && kok) fa = *reinterpret_cast<const u32x4*>(A + k);
-      u32x4 fw[NG];
+    // UNR K-steps of operand fragments are requested before the first MFMA of the group: the kernel is
+    // latency bound (every fragment comes from L2 exactly once), so bytes in flight per wave are the lever.
+    constexpr int UNR = 4;
+    for (int s0 = 0; s0 < nsteps; s0 += UNR) {
+      u32x4 fa[UNR], fw[UNR][NG];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        fw[g] = u32x4{0u, 0u, 0u, 0u};
-        if (nok && kok) fw[g] = *reinterpret_cast<const u32x4*>(W + g * gs + k);
+      for (int u = 0; u < UNR; ++u) {
+        const int k = ((s0 + u) * 4 + q4) * EPC;
+        const bool kok = k < K;
+        fa[u] = u32x4{0u, 0u, 0u, 0u};
+        if (mok && kok) fa[u] = *reinterpret_cast<const u32x4*>(A + k);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          fw[u][g] = u32x4{0u, 0u, 0u, 0u};
+          if (nok && kok) fw[u][g] = *reinterpret_cast<const u32x4*>(W + g * gs + k);
+        }
       }
 #pragma unroll
-      for (int g = 0; g < NG; ++g) Mfma<T>::run(fw[g], fa, acc[g]);
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) Mfma<T>::run(fw[u][g], fa[u], acc[g]);
     }
   };
   pass(a.A, a.W, a.K, a.lda, a.ldw, accH);
@@ -93,10 +101,10 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0,
 // EPI 1: GRU gates (training fwd with precomputed gx, or decode with fused x-projection)
 // EPI 2: LSTM gates
 template <typename T, int NG, int EPI, bool HAS_X>
-__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmArgs a) {
+__global__ __launch_bounds__(128) void rnn_gemm_kernel(RnnGemmArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r16 = lane & 15, q4 = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64 + wid * 16;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32 + wid * 16;
   if (m0 >= a.M) return;
   f32x4 accH[NG], accX[NG];
 #pragma unroll
@@ -383,7 +391,7 @@ int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStre
   const int epc = dtype == ST_BF16 ? 8 : 4;
   ST_CHECK(a.K % epc == 0 && a.lda % epc == 0 && a.ldw % epc == 0, "rnn_gemm: K/lda/ldw must be multiples of %d", epc);
   if (has_x) ST_CHECK(a.K2 % epc == 0 && a.lda2 % epc == 0 && a.ldw2 % epc == 0, "rnn_gemm: K2/lda2/ldw2 must be multiples of %d", epc);
-  const dim3 grid((a.N + 15) / 16, (a.M + 63) / 64), block(256);
+  const dim3 grid((a.N + 15) / 16, (a.M + 31) / 32), block(128);
 #define RG(T, NG, EPI, HX) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX>), grid, block, 0, st, a)
   if (dtype == ST_BF16) {
     if (epi == 0) RG(bf16_t, 1, 0, false);
