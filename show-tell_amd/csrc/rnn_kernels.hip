@@ -9,7 +9,7 @@
 //   main.py:149    nn.CrossEntropyLoss (fwd + bwd)               -> ce_kernel
 //
 // The recurrent product h_{t-1} W_hh^T has only B_t <= batch rows, so it is launch/latency
-// bound, not FLOP bound: one block owns 16 hidden units (all gates of those units) x 32 batch
+// bound, not FLOP bound: one block owns 16 hidden units (all gates of those units) x 16 batch
 // rows, operands go straight from L2 to MFMA fragments (no LDS: each fragment is used once),
 // and the whole gate nonlinearity runs in the epilogue so a timestep is ONE launch.
 #include "common.h"
@@ -59,7 +59,7 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x))
 // skinny GEMM  acc[g][m][n] = sum_k A[m][k] * W[g*gstride + n][k]   (+ optional second pair)
 // ---------------------------------------------------------------------------------------
 template <typename T, int NG, bool HAS_X>
-__device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0, int r16, int q4,
+__device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0, int r16, int q4, int kslice,
                                            f32x4 (&accH)[NG], f32x4 (&accX)[NG]) {
   constexpr int EPC = Mfma<T>::EPC;
   const int m = m0 + r16, n = n0 + r16;
@@ -73,12 +73,14 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0,
     // UNR K-steps of operand fragments are requested before the first MFMA of the group: the kernel is
     // latency bound (every fragment comes from L2 exactly once), so bytes in flight per wave are the lever.
     constexpr int UNR = 4;
-    for (int s0 = 0; s0 < nsteps; s0 += UNR) {
+    const int spw = (nsteps + 3) / 4;                       // K is split over the block's 4 waves
+    const int send = min(nsteps, (kslice + 1) * spw);
+    for (int s0 = kslice * spw; s0 < send; s0 += UNR) {
       u32x4 fa[UNR], fw[UNR][NG];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int k = ((s0 + u) * 4 + q4) * EPC;
-        const bool kok = k < K;
+        const bool kok = k < K && s0 + u < send;
         fa[u] = u32x4{0u, 0u, 0u, 0u};
         if (mok && kok) fa[u] = *reinterpret_cast<const u32x4*>(A + k);
 #pragma unroll
@@ -101,15 +103,31 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0,
 // EPI 1: GRU gates (training fwd with precomputed gx, or decode with fused x-projection)
 // EPI 2: LSTM gates
 template <typename T, int NG, int EPI, bool HAS_X>
-__global__ __launch_bounds__(128) void rnn_gemm_kernel(RnnGemmArgs a) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmArgs a) {
+  // block = 16 rows x 16 units (all NG gates); its 4 waves each take a quarter of K and the partial
+  // accumulators meet in LDS: one round of L2 latency per launch instead of four.
+  __shared__ f32x4 red[3][2 * NG][64];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r16 = lane & 15, q4 = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32 + wid * 16;
-  if (m0 >= a.M) return;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
   f32x4 accH[NG], accX[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) { accH[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accX[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  skinny_mma<T, NG, HAS_X>(a, m0, n0, r16, q4, accH, accX);
+  skinny_mma<T, NG, HAS_X>(a, m0, n0, r16, q4, wid, accH, accX);
+  if (wid > 0) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { red[wid - 1][g][lane] = accH[g]; if (HAS_X) red[wid - 1][NG + g][lane] = accX[g]; }
+  }
+  __syncthreads();
+  if (wid > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      accH[g] += red[w][g][lane];
+      if (HAS_X) accX[g] += red[w][NG + g][lane];
+    }
 
   // lane owns row m = m0 + r16 and units n = n0 + 4*q4 + {0..3}
   const int m = m0 + r16, n = n0 + 4 * q4;
@@ -391,7 +409,7 @@ int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStre
   const int epc = dtype == ST_BF16 ? 8 : 4;
   ST_CHECK(a.K % epc == 0 && a.lda % epc == 0 && a.ldw % epc == 0, "rnn_gemm: K/lda/ldw must be multiples of %d", epc);
   if (has_x) ST_CHECK(a.K2 % epc == 0 && a.lda2 % epc == 0 && a.ldw2 % epc == 0, "rnn_gemm: K2/lda2/ldw2 must be multiples of %d", epc);
-  const dim3 grid((a.N + 15) / 16, (a.M + 31) / 32), block(128);
+  const dim3 grid((a.N + 15) / 16, (a.M + 15) / 16), block(256);
 #define RG(T, NG, EPI, HX) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX>), grid, block, 0, st, a)
   if (dtype == ST_BF16) {
     if (epi == 0) RG(bf16_t, 1, 0, false);
