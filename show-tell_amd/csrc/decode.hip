@@ -125,6 +125,99 @@ __global__ __launch_bounds__(256) void softmax_topk_kernel(const float* __restri
   }
 }
 
+
+// Vocabulary projection with a fused running arg-max: logits[m][n] = h[m] . W[n] + b[n] are never written; per row the
+// (value, first index) maximum is merged into a packed 64-bit key by atomic max.  One block = 16 rows x 128 vocabulary
+// entries; a wave owns two 16-entry tiles and requests all of a tile's K fragments before its first MFMA.
+template <typename T> struct MfmaD;
+template <> struct MfmaD<bf16_t> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct MfmaD<float> {
+  static constexpr int EPC = 4;
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void vocab_argmax_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                           const float* __restrict__ bias, int M, int N, int K,
+                                                           unsigned long long* __restrict__ keys) {
+  constexpr int EPC = MfmaD<T>::EPC, UNR = 16;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  // 1-D grid: blocks that share a 128-entry slice of W are 8 apart (same XCD under round-robin placement), so the
+  // slice is fetched into ONE L2 and re-used by the other row tiles (speed only, any placement is correct)
+  const int nmt = (M + 15) / 16;
+  const int grp = blockIdx.x / (8 * nmt), rem = blockIdx.x - grp * 8 * nmt;
+  const int nslice = grp * 8 + (rem & 7), mt = rem >> 3;
+  const int m0 = mt * 16, m = m0 + r16;
+  const bool mok = m < M;
+  const T* Ar = A + (long)m * lda;
+  const int nsteps = (K + 4 * EPC - 1) / (4 * EPC);
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int tt = 0; tt < 2; ++tt) {
+    const int n0 = ((nslice * 4 + wid) * 2 + tt) * 16;
+    if (n0 >= N) break;
+    const int nr = n0 + r16;
+    const bool nok = nr < N;
+    const T* Wr = W + (long)nr * ldw;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < nsteps; s0 += UNR) {
+      u32x4 fa[UNR], fw[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int k = ((s0 + u) * 4 + q4) * EPC;
+        const bool kok = k < K;
+        fa[u] = u32x4{0u, 0u, 0u, 0u}; fw[u] = u32x4{0u, 0u, 0u, 0u};
+        if (mok && kok) fa[u] = *reinterpret_cast<const u32x4*>(Ar + k);
+        if (nok && kok) fw[u] = *reinterpret_cast<const u32x4*>(Wr + k);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) MfmaD<T>::run(fw[u], fa[u], acc);
+    }
+    const int n = n0 + 4 * q4;      // lane: row m, entries n .. n+3
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e < N) {
+        const float v = acc[e] + bias[n + e];
+        if (v > best || (v == best && n + e < bi)) { best = v; bi = n + e; }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (q4 == 0 && mok && bi != 0x7fffffff) {
+    unsigned u = __float_as_uint(best);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    atomicMax(keys + m, ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi));
+  }
+}
+
+// packed (value, index) maxima -> token ids of step t, next-step embedding rows; keys are re-armed (0) for the next step
+template <typename T>
+__global__ __launch_bounds__(256) void keys_to_ids_embed_kernel(unsigned long long* __restrict__ keys, long* __restrict__ ids,
+                                                                int ids_stride, int t, const T* __restrict__ emb, T* __restrict__ x,
+                                                                int E, int V) {
+  const int row = blockIdx.x;
+  const unsigned long long key = keys[row];
+  int bi = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+  if (bi < 0 || bi >= V) bi = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) { ids[(long)row * ids_stride + t] = bi; keys[row] = 0ull; }
+  constexpr int N = 16 / (int)sizeof(T);
+  for (int c = threadIdx.x * N; c < E; c += blockDim.x * N)
+    *reinterpret_cast<u32x4*>(x + (long)row * E + c) = *reinterpret_cast<const u32x4*>(emb + (long)bi * E + c);
+}
+
 int gemm_nt(const void* a, int lda, const void* w, int ldw, void* y, int ldy, int M, int N, int K, int dtype, int out_dtype,
             const float* bias, void* stream) {
   st_conv_desc d;
@@ -141,7 +234,7 @@ extern "C" size_t st_rnn_greedy_workspace_bytes(const st_rnn_params* p, int B) {
   if (!p || B <= 0) return 0;
   const size_t es = st_dtype_size(p->dtype);
   const size_t hb = al((size_t)p->L * B * p->H * es);
-  return 4 * hb + al((size_t)B * p->E * es) + al((size_t)B * up8(p->V) * sizeof(float));
+  return 4 * hb + al((size_t)B * p->E * es) + al((size_t)B * up8(p->V) * sizeof(float)) + al((size_t)B * sizeof(unsigned long long));
 }
 
 extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, int steps, void* workspace, size_t workspace_bytes,
@@ -160,6 +253,8 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
   char* cbuf[2] = {ws + 2 * hb, ws + 3 * hb};
   char* xbuf = ws + 4 * hb;
   float* logits = reinterpret_cast<float*>(xbuf + al((size_t)B * E * es));
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(logits) + al((size_t)B * Vp * sizeof(float)));
+  if (!logits_out && hipMemsetAsync(keys, 0, (size_t)B * sizeof(unsigned long long), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
   const void* x = feat;
   int cur = 0;
   for (int t = 0; t < steps; ++t) {
@@ -181,7 +276,26 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
       }
       if (rnn_gemm_launch(a, dt, p->cell == ST_CELL_GRU ? 1 : 2, 1, st)) return 1;
     }
-    float* lg = logits_out ? logits_out + (size_t)t * B * Vp : logits;
+    if (!logits_out) {
+      // fast path: vocabulary projection with a fused running arg-max (the logits are never written)
+      const int nsl = (V + 127) / 128, nmt = (B + 15) / 16;
+      const dim3 vgrid(((nsl + 7) / 8) * 8 * nmt);
+      const char* htop = hbuf[nxt] + (size_t)(L - 1) * B * H * es;
+      if (dt == ST_BF16)
+        hipLaunchKernelGGL(vocab_argmax_kernel<bf16_t>, vgrid, dim3(256), 0, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, keys);
+      else
+        hipLaunchKernelGGL(vocab_argmax_kernel<float>, vgrid, dim3(256), 0, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, keys);
+      ST_LAUNCH_CHECK();
+      if (dt == ST_BF16)
+        hipLaunchKernelGGL(keys_to_ids_embed_kernel<bf16_t>, dim3(B), dim3(64), 0, st, keys, ids_out, steps, t, (const bf16_t*)p->emb, (bf16_t*)xbuf, E, V);
+      else
+        hipLaunchKernelGGL(keys_to_ids_embed_kernel<float>, dim3(B), dim3(64), 0, st, keys, ids_out, steps, t, (const float*)p->emb, (float*)xbuf, E, V);
+      ST_LAUNCH_CHECK();
+      x = xbuf;
+      cur = nxt;
+      continue;
+    }
+    float* lg = logits_out + (size_t)t * B * Vp;
     if (gemm_nt(hbuf[nxt] + (size_t)(L - 1) * B * H * es, H, p->w_lin, H, lg, Vp, B, V, H, dt, ST_F32, p->b_lin, stream)) return 1;
     if (dt == ST_BF16)
       hipLaunchKernelGGL(argmax_embed_kernel<bf16_t>, dim3(B), dim3(256), 0, st, lg, Vp, V, ids_out, steps, t, (const bf16_t*)p->emb, (bf16_t*)xbuf, E);

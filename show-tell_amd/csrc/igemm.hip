@@ -67,10 +67,24 @@ template <> struct Mfma<float> {
 
 // ---- epilogue shared by both main loops ---------------------------------------------------------
 // On entry every wave has passed a barrier after its last LDS read of the K loop and no LDS-DMA is in flight.
-template <typename T, int BM, int BN, int WM, int WN>
+// RAWB: barriers are raw s_barrier + lgkmcnt(0) (an LDS-DMA ring may be in flight: __syncthreads() would drain it);
+// only waves [SW0, SW0+SNW) touch global memory (their vmcnt then never mixes with the DMA waves' counted waits).
+template <bool RAWB> __device__ __forceinline__ void epi_barrier() {
+  if (RAWB) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool RAWB = false, int SW0 = 0, int SNW = WM * WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
                                                int bm, int bn, int tid) {
-  constexpr int NT = 64 * WM * WN;
+  constexpr int NT = 64 * SNW;                       // threads that store
+  const int stid = tid - 64 * SW0;                   // store-thread index (negative / >= NT: not a storer)
+  const bool storer = stid >= 0 && stid < NT;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid - wm * WN;
@@ -107,8 +121,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         }
       }
     }
-    __syncthreads();
-    for (int t = tid; t < 2 * BN; t += NT) {
+    epi_barrier<RAWB>();
+    if (storer) for (int t = stid; t < 2 * BN; t += NT) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) v += red[t * WM + w];
@@ -127,7 +141,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
   const int lrow0 = (wm * (BM / WM)) % 64;           // this wave's first row inside its half
 #pragma unroll
   for (int h = 0; h < HALVES; ++h) {
-    __syncthreads();                                  // stats reduction / previous half has left the buffer
+    epi_barrier<RAWB>();                              // stats reduction / previous half has left the buffer
     if (my_half == h) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -148,11 +162,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
           *reinterpret_cast<f32x4*>(stage + (lrow0 + i * 16 + r16) * SROW + nl) = v;
         }
     }
-    __syncthreads();
+    epi_barrier<RAWB>();
     constexpr int CPR = BN / 8;                       // 8-channel chunks per row
     constexpr int RPI = NT / CPR;                     // rows per pass
-    const int c8 = (tid % CPR) * 8, rr = tid / CPR;
+    const int c8 = (stid % CPR) * 8, rr = stid / CPR;
     const int n = bn * BN + c8;
+    if (storer)
 #pragma unroll
     for (int r = rr; r < 64; r += RPI) {
       const int m = bm * BM + h * 64 + r;
@@ -545,6 +560,155 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_ring_kernel(IgemmArgs a) {
   igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
 }
 
+// =======================================================================================
+// Main loop 3: PERSISTENT LDS-DMA ring.  One 8-wave block per CU walks a list of 128x128 output tiles; the
+// K-tile stream of the ring continues ACROSS tile boundaries, so the first K-tiles of the next tile (and its
+// row set-up) are already in flight while the current tile's MFMAs and epilogue run: launch/prologue latency
+// is paid once per kernel, not once per tile.
+//   * waves 0-3 issue the DMA (8 x 1 KiB pieces per K-tile each) and own the counted vmcnt waits;
+//   * waves 4-7 do all global stores / atomics of the epilogue.  vmcnt is per wave and in order, so keeping
+//     stores out of the DMA waves keeps their counts exact; the store waves never wait on memory;
+//   * all 8 waves run the MFMAs (wave tile 64x32); epilogue barriers are raw (s_barrier + lgkmcnt(0)) and its
+//     staging buffer lives outside the ring.
+// Requires the FAST address walk (Cin % 64 == 0 for bf16).
+// =======================================================================================
+template <typename T, int NS>
+__global__ __launch_bounds__(512) void igemm_pring_kernel(IgemmArgs a) {
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 4, NW = 8, NLW = 4;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  constexpr int PA = BM / (8 * NLW), PB = BN / (8 * NLW);
+  constexpr int G = PA + PB;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int TILE_BYTES = (BM + BN) * 128;
+  static_assert((NS - 1) * G <= 63, "vmcnt range");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const epi_smem = smem + NS * TILE_BYTES;
+
+  const int ntiles = a.nbm * a.nbn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid - wm * WN;
+  const bool loader = wid < NLW;
+  const int nk = (a.K + BK - 1) / BK;
+  const int ntap = a.KH * a.KW;
+
+  auto tile_coords = [&](int t, int& bm, int& bn) {     // XCD-aware tile order (bijective)
+    const int xcd = t & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    bm = lid / a.nbn; bn = lid - bm * a.nbn;
+  };
+
+  // ---- issue side (loader waves): per-tile row set-up + block-uniform tap walk ------------------------
+  const int prow = lane >> 3, ccol = (lane & 7) ^ prow;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
+  const T* Z = reinterpret_cast<const T*>(g_zero16);
+  const T* arow[PA]; unsigned long long amask[PA]; const T* wptr[PB];
+  const int HoWo = a.Ho * a.Wo;
+  int it_tile = blockIdx.x, it_kt = 0;
+  int kc = 0, kh = 0, kw = 0, tap = 0, klin = 0;
+  long tapoff = 0;
+  auto setup_tile = [&](int t) {
+    int bm, bn;
+    tile_coords(t, bm, bn);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int m = bm * BM + (wid + NLW * i) * 8 + prow;
+      arow[i] = X; amask[i] = 0ull;
+      if (m < a.M) {
+        const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+        arow[i] = X + ((long)(b * a.Hin * a.Win + hi0 * a.Win + wi0) * a.ldx + ccol * EPC);
+        for (int fh = 0; fh < a.KH; ++fh)
+          for (int fw = 0; fw < a.KW; ++fw)
+            if ((unsigned)(hi0 + fh) < (unsigned)a.Hin && (unsigned)(wi0 + fw) < (unsigned)a.Win)
+              amask[i] |= 1ull << (fh * a.KW + fw);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int n = bn * BN + (wid + NLW * i) * 8 + prow;
+      wptr[i] = n < a.N ? W + ((long)n * a.ldw + ccol * EPC) : nullptr;
+    }
+    kc = 0; kh = 0; kw = 0; tap = 0; klin = 0; tapoff = 0;
+  };
+  auto issue = [&](int slot) {
+    if (!loader) return;
+    char* base = smem + slot * TILE_BYTES;
+    const bool live = it_tile < ntiles;
+    const bool kok = live && (a.korder ? kc < a.Cin : tap < ntap);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const T* cand = arow[i] + (tapoff + kc);
+      const T* src = (kok && ((amask[i] >> tap) & 1ull)) ? cand : Z;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (wid + NLW * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const T* src = (kok && wptr[i]) ? wptr[i] + klin : Z;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + BM * 128 + (wid + NLW * i) * 1024), 16, 0, 0);
+    }
+    if (!live) return;
+    klin += BK;
+    if (a.korder) {
+      ++tap; if (++kw == a.KW) { kw = 0; ++kh; }
+      if (tap == ntap) { tap = 0; kh = 0; kw = 0; kc += BK; }
+      tapoff = (long)(kh * a.Win + kw) * a.ldx;
+    } else {
+      kc += BK;
+      if (kc >= a.Cin) { kc = 0; ++tap; if (++kw == a.KW) { kw = 0; ++kh; } tapoff = (long)(kh * a.Win + kw) * a.ldx; }
+    }
+    if (++it_kt == nk) {                                // next K-tile belongs to the block's next output tile
+      it_kt = 0;
+      it_tile += gridDim.x;
+      if (it_tile < ntiles) setup_tile(it_tile);
+    }
+  };
+
+  if (loader && it_tile < ntiles) setup_tile(it_tile);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+
+  const int r16 = lane & 15, q4 = lane >> 4;
+  int g = 0;                                            // K-tiles consumed by this block so far
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      if (loader) wait_vmcnt<(NS - 2) * G>();           // K-tile g has landed (this wave's pieces)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // ... everybody's; the slot of K-tile g-1 is free
+      asm volatile("" ::: "memory");
+      issue((g + NS - 1) % NS);
+      const char* base = smem + (g % NS) * TILE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int so = ((ks * 4 + q4) ^ (r16 & 7)) << 4;
+        u32x4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[i] = *reinterpret_cast<const u32x4*>(base + (wm * (BM / WM) + i * 16 + r16) * 128 + so);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[j] = *reinterpret_cast<const u32x4*>(base + (BM + wn * (BN / WN) + j * 16 + r16) * 128 + so);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+      }
+    }
+    int bm, bn;
+    tile_coords(tile, bm, bn);
+    igemm_epilogue<T, BM, BN, WM, WN, true, NLW, NW - NLW>(a, acc, epi_smem, bm, bn, tid);
+  }
+  if (loader) wait_vmcnt<0>();                          // over-issued all-zero K-tiles
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool FAST>
 int launch_(IgemmArgs& a, hipStream_t st) {
   a.nbm = (a.M + BM - 1) / BM;
@@ -613,6 +777,43 @@ int launch_ring_(IgemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <typename T, int NS>
+int launch_pring(IgemmArgs& a, hipStream_t st) {
+  a.nbm = (a.M + 127) / 128;
+  a.nbn = (a.N + 127) / 128;
+  constexpr int lds = NS * 256 * 128 + 64 * (128 + 4) * 4 + 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pring_kernel<T, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  const int ntiles = a.nbm * a.nbn;
+  const int grid = ntiles < ncu ? ntiles : ncu;
+  constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + 3;
+  ProfRec rec; bool prof = false;
+  if (g_prof_on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.size() < kProfMax && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
+      rec.variant = variant; rec.flops = a.flops; prof = true;
+      (void)hipEventRecord(rec.e0, st);
+    }
+  }
+  hipLaunchKernelGGL((igemm_pring_kernel<T, NS>), dim3(grid), dim3(512), lds, st, a);
+  if (prof) {
+    (void)hipEventRecord(rec.e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(rec);
+  }
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NS>
 int launch_ring(IgemmArgs& a, hipStream_t st) {
   constexpr int BK = 8 * (16 / (int)sizeof(T));
@@ -650,6 +851,11 @@ int dispatch(IgemmArgs& a, hipStream_t st) {
   if (ring == 13 && a.N > 64) return launch_ring<T, 128, 128, 2, 4, 3>(a, st);
   if (ring == 14 && a.N > 64) return launch_ring<T, 128, 128, 2, 4, 4>(a, st);
   if (ring == 23 && a.N > 64) return launch_ring<T, 256, 128, 4, 2, 3>(a, st);
+  {
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    const bool fast = (a.Cin % BK == 0) && a.KH * a.KW <= 64;
+    if (ring == 33 && a.N > 64 && fast) return launch_pring<T, 3>(a, st);
+  }
   const int kc = tuning_kc();
   if (kc == 4 && !a.korder) return dispatch_kc<T, 4>(a, st);
   return dispatch_kc<T, 8>(a, st);

@@ -15,6 +15,7 @@ struct RnnGemmArgs {
   void* hout; void* cout; int ldho;
   void* hout2; int ldho2;              // optional second copy of h' (decode: running state + layer output)
   void* cache; int ldcache;            // saved gates for BPTT (NULL at inference)
+  unsigned long long* argmax_keys;     // EPI 3: per-row packed (value, index) maxima
 };
 
 int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st);

@@ -62,41 +62,56 @@ template <typename T, int NG, bool HAS_X>
 __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0, int r16, int q4, int kslice,
                                            f32x4 (&accH)[NG], f32x4 (&accX)[NG]) {
   constexpr int EPC = Mfma<T>::EPC;
+  constexpr int UNR = 4;
   const int m = m0 + r16, n = n0 + r16;
   const bool mok = m < a.M, nok = n < a.N;
-  auto pass = [&](const void* Ap, const void* Wp, int K, int lda, int ldw, f32x4 (&acc)[NG]) {
-    if (!Ap) return;
-    const T* A = reinterpret_cast<const T*>(Ap) + (long)m * lda;
-    const T* W = reinterpret_cast<const T*>(Wp) + (long)n * ldw;
-    const long gs = (long)a.gstride * ldw;
-    const int nsteps = (K + 4 * EPC - 1) / (4 * EPC);
-    // UNR K-steps of operand fragments are requested before the first MFMA of the group: the kernel is
-    // latency bound (every fragment comes from L2 exactly once), so bytes in flight per wave are the lever.
-    constexpr int UNR = 4;
-    const int spw = (nsteps + 3) / 4;                       // K is split over the block's 4 waves
-    const int send = min(nsteps, (kslice + 1) * spw);
-    for (int s0 = kslice * spw; s0 < send; s0 += UNR) {
-      u32x4 fa[UNR], fw[UNR][NG];
+  // The kernel is latency bound (every fragment comes from L2 exactly once), so bytes in flight per wave are the
+  // lever: K is split over the block's 4 waves and a group of UNR K-steps of BOTH operand pairs (h W_hh and, in
+  // the decode form, x W_ih) is requested before the first MFMA of the group -- one round trip per group.
+  const bool hasH = a.A != nullptr, hasX = HAS_X && a.A2 != nullptr;
+  const T* AH = reinterpret_cast<const T*>(a.A) + (long)m * a.lda;
+  const T* WH = reinterpret_cast<const T*>(a.W) + (long)n * a.ldw;
+  const long gsH = (long)a.gstride * a.ldw;
+  const T* AX = reinterpret_cast<const T*>(a.A2) + (long)m * a.lda2;
+  const T* WX = reinterpret_cast<const T*>(a.W2) + (long)n * a.ldw2;
+  const long gsX = (long)a.gstride * a.ldw2;
+  const int nsH = hasH ? (a.K + 4 * EPC - 1) / (4 * EPC) : 0, nsX = hasX ? (a.K2 + 4 * EPC - 1) / (4 * EPC) : 0;
+  const int spwH = (nsH + 3) / 4, spwX = (nsX + 3) / 4;
+  const int begH = kslice * spwH, endH = min(nsH, begH + spwH), begX = kslice * spwX, endX = min(nsX, begX + spwX);
+  const int ngroups = max((endH - begH + UNR - 1) / UNR, (endX - begX + UNR - 1) / UNR);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    u32x4 fa[UNR], fw[UNR][NG], xa[UNR], xw[UNR][NG];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int k = ((s0 + u) * 4 + q4) * EPC;
-        const bool kok = k < K && s0 + u < send;
-        fa[u] = u32x4{0u, 0u, 0u, 0u};
-        if (mok && kok) fa[u] = *reinterpret_cast<const u32x4*>(A + k);
+    for (int u = 0; u < UNR; ++u) {
+      const int sH = begH + gi * UNR + u, kH = (sH * 4 + q4) * EPC;
+      const bool okH = sH < endH && kH < a.K;
+      fa[u] = u32x4{0u, 0u, 0u, 0u};
+      if (mok && okH) fa[u] = *reinterpret_cast<const u32x4*>(AH + kH);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        fw[u][g] = u32x4{0u, 0u, 0u, 0u};
+        if (nok && okH) fw[u][g] = *reinterpret_cast<const u32x4*>(WH + g * gsH + kH);
+      }
+      if (HAS_X) {
+        const int sX = begX + gi * UNR + u, kX = (sX * 4 + q4) * EPC;
+        const bool okX = sX < endX && kX < a.K2;
+        xa[u] = u32x4{0u, 0u, 0u, 0u};
+        if (mok && okX) xa[u] = *reinterpret_cast<const u32x4*>(AX + kX);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          fw[u][g] = u32x4{0u, 0u, 0u, 0u};
-          if (nok && kok) fw[u][g] = *reinterpret_cast<const u32x4*>(W + g * gs + k);
+          xw[u][g] = u32x4{0u, 0u, 0u, 0u};
+          if (nok && okX) xw[u][g] = *reinterpret_cast<const u32x4*>(WX + g * gsX + kX);
         }
       }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) Mfma<T>::run(fw[u][g], fa[u], acc[g]);
     }
-  };
-  pass(a.A, a.W, a.K, a.lda, a.ldw, accH);
-  if (HAS_X) pass(a.A2, a.W2, a.K2, a.lda2, a.ldw2, accX);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        Mfma<T>::run(fw[u][g], fa[u], accH[g]);
+        if (HAS_X) Mfma<T>::run(xw[u][g], xa[u], accX[g]);
+      }
+  }
 }
 
 // EPI 0: out_f32[m][n] (+)= acc (+bias)         (BPTT dh += dgh W_hh, generic small products)
@@ -114,6 +129,30 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmArgs a) {
   f32x4 accH[NG], accX[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) { accH[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accX[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // wave 0 owns the epilogue: its operands (biases, precomputed x-projection, previous state) are requested
+  // BEFORE the fragment loads so that they arrive under the same round trip
+  const int pm = m0 + r16, pn = n0 + 4 * q4;
+  const bool epi_ok = wid == 0 && pm < a.M && pn < a.N && EPI != 3;
+  float ex[NG][4], eb[NG][4], es[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ex[g][e] = 0.f; eb[g][e] = 0.f; }
+  if (epi_ok) {
+    if (EPI == 0) {
+      if (a.bias_h) load4<float>(a.bias_h + pn, eb[0]);
+      if (a.accumulate) load4<float>(a.out_f32 + (long)pm * a.ldo + pn, es);
+    } else {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        load4<float>(a.bias_h + g * a.N + pn, eb[g]);
+        if (HAS_X) load4<float>(a.bias_x + g * a.N + pn, ex[g]);
+        else load4<T>(reinterpret_cast<const T*>(a.gx) + (long)pm * a.ldgx + g * a.N + pn, ex[g]);   // already holds b_ih
+      }
+      const void* prev = EPI == 1 ? a.hprev : a.cprev;
+      if (prev) load4<T>(reinterpret_cast<const T*>(prev) + (long)pm * a.ldhp + pn, es);
+    }
+  }
   skinny_mma<T, NG, HAS_X>(a, m0, n0, r16, q4, wid, accH, accX);
   if (wid > 0) {
 #pragma unroll
@@ -131,32 +170,50 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmArgs a) {
 
   // lane owns row m = m0 + r16 and units n = n0 + 4*q4 + {0..3}
   const int m = m0 + r16, n = n0 + 4 * q4;
-  if (m >= a.M || n >= a.N) return;
+  if (EPI != 3 && (m >= a.M || n >= a.N)) return;
   const int H = a.N;
+  if (EPI == 3) {
+    // greedy decoding: the logits are never written; (value, first index) per row by 64-bit atomic max
+    float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e < a.N) {
+        const float v = accH[0][e] + (a.bias_h ? a.bias_h[n + e] : 0.f);
+        if (v > best) { best = v; bi = n + e; }
+      }
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (q4 == 0 && bi != 0x7fffffff && m < a.M) {   // rows past M took part in the shuffles only
+      unsigned u = __float_as_uint(best);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      const unsigned long long key = ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi);
+      atomicMax(a.argmax_keys + m, key);
+    }
+    return;
+  }
   if (EPI == 0) {
     float* o = a.out_f32 + (long)m * a.ldo + n;
     float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = accH[0][e] + (a.bias_h ? a.bias_h[n + e] : 0.f) + (a.accumulate ? o[e] : 0.f);
+    for (int e = 0; e < 4; ++e) v[e] = accH[0][e] + eb[0][e] + es[e];
     *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
   } else if (EPI == 1) {
     // r,z,n order (torch.nn.GRU): r = s(xr+hr), z = s(xz+hz), n = tanh(xn + r*(hn)), h' = (1-z) n + z h
-    float xg[3][4], hp[4] = {0.f, 0.f, 0.f, 0.f};
+    float xg[3][4];
+    const float* hp = es;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      if (HAS_X) {
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xg[g][e] = accX[g][e] + a.bias_x[g * H + n + e];
-      } else {
-        load4<T>(reinterpret_cast<const T*>(a.gx) + (long)m * a.ldgx + g * H + n, xg[g]);  // already holds b_ih
-      }
-    }
-    if (a.hprev) load4<T>(reinterpret_cast<const T*>(a.hprev) + (long)m * a.ldhp + n, hp);
+      for (int e = 0; e < 4; ++e) xg[g][e] = (HAS_X ? accX[g][e] : 0.f) + ex[g][e];
     float hn[4], r[4], z[4], nn[4], hnew[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float hr = accH[0][e] + a.bias_h[n + e], hz = accH[1][e] + a.bias_h[H + n + e];
-      hn[e] = accH[2][e] + a.bias_h[2 * H + n + e];
+      const float hr = accH[0][e] + eb[0][e], hz = accH[1][e] + eb[1][e];
+      hn[e] = accH[2][e] + eb[2][e];
       r[e] = sigm(xg[0][e] + hr);
       z[e] = sigm(xg[1][e] + hz);
       nn[e] = tanhf(xg[2][e] + r[e] * hn[e]);
@@ -170,19 +227,12 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmArgs a) {
     }
   } else {
     // i,f,g,o order (torch.nn.LSTM): c' = f c + i g ; h' = o tanh(c')
-    float pre[4][4], cp[4] = {0.f, 0.f, 0.f, 0.f};
+    float pre[4][4];
+    const float* cp = es;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (HAS_X) {
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pre[g][e] = accX[g][e] + a.bias_x[g * H + n + e];
-      } else {
-        load4<T>(reinterpret_cast<const T*>(a.gx) + (long)m * a.ldgx + g * H + n, pre[g]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pre[g][e] += accH[g][e] + a.bias_h[g * H + n + e];
-    }
-    if (a.cprev) load4<T>(reinterpret_cast<const T*>(a.cprev) + (long)m * a.ldhp + n, cp);
+      for (int e = 0; e < 4; ++e) pre[g][e] = (HAS_X ? accX[g][e] : 0.f) + ex[g < NG ? g : 0][e] + accH[g < NG ? g : 0][e] + eb[g < NG ? g : 0][e];
     float ig[4], fg[4], gg[4], og[4], cn[4], hnew[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -405,7 +455,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 // ---------------------------------------------------------------------------------------
 int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st) {
   if (a.M <= 0) return 0;
-  ST_CHECK(a.N % 4 == 0, "rnn_gemm: N=%d must be a multiple of 4", a.N);
+  ST_CHECK(epi == 3 || a.N % 4 == 0, "rnn_gemm: N=%d must be a multiple of 4", a.N);
   const int epc = dtype == ST_BF16 ? 8 : 4;
   ST_CHECK(a.K % epc == 0 && a.lda % epc == 0 && a.ldw % epc == 0, "rnn_gemm: K/lda/ldw must be multiples of %d", epc);
   if (has_x) ST_CHECK(a.K2 % epc == 0 && a.lda2 % epc == 0 && a.ldw2 % epc == 0, "rnn_gemm: K2/lda2/ldw2 must be multiples of %d", epc);
@@ -413,10 +463,12 @@ int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStre
 #define RG(T, NG, EPI, HX) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX>), grid, block, 0, st, a)
   if (dtype == ST_BF16) {
     if (epi == 0) RG(bf16_t, 1, 0, false);
+    else if (epi == 3) RG(bf16_t, 1, 3, false);
     else if (epi == 1) { if (has_x) RG(bf16_t, 3, 1, true); else RG(bf16_t, 3, 1, false); }
     else { if (has_x) RG(bf16_t, 4, 2, true); else RG(bf16_t, 4, 2, false); }
   } else {
     if (epi == 0) RG(float, 1, 0, false);
+    else if (epi == 3) RG(float, 1, 3, false);
     else if (epi == 1) { if (has_x) RG(float, 3, 1, true); else RG(float, 3, 1, false); }
     else { if (has_x) RG(float, 4, 2, true); else RG(float, 4, 2, false); }
   }
