@@ -143,6 +143,37 @@ def main():
                 "avg_launch_us": round(ms[v] * 1e3 / max(1, n[v]), 2),
                 "all_igemm_TFLOPs": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                 "all_igemm_ms_per_step": round(tot_ms / max(1, a.profile_steps), 3)}
+    # ---- secondary (rank 0, N=1): greedy decode step against the HBM roofline, beam=5 captions/sec -------------
+    secondary = None
+    if rank == 0 and world == 1:
+        try:
+            rnn.eval()
+            feat = torch.randn(B, E, device=dev)
+            for _ in range(2):
+                rnn.sentence_index(feat)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record()
+            for _ in range(reps):
+                rnn.sentence_index(feat)
+            e1.record(); torch.cuda.synchronize()
+            us_step = e0.elapsed_time(e1) / reps / 25 * 1e3
+            nw = sum(p.numel() for n_, p in rnn.named_parameters() if not n_.startswith("embeddings"))
+            byts = (nw + 2 * L * B * H + B * E) * 2 + 16 * B            # 27.46 MB/step in bf16
+            f256 = torch.randn(256, E, device=dev)
+            rnn.beam_search(f256[:8], 5, 1, 25)
+            torch.cuda.synchronize(); tb = time.perf_counter()
+            rnn.beam_search(f256, 5, 1, 25)
+            torch.cuda.synchronize(); tb = time.perf_counter() - tb
+            secondary = {"greedy_decode_us_per_step": round(us_step, 1), "greedy_algorithmic_MB_per_step": round(byts / 1e6, 2),
+                         "greedy_hbm_roofline": {"bound": "hbm", "achieved": round(byts / us_step / 1e3, 1), "peak": 8000.0,
+                                                 "unit": "GB/s", "frac": round(byts / us_step / 1e3 / 8000.0, 4)},
+                         "greedy_captions_per_sec": round(B / (us_step * 25e-6), 0),
+                         "beam5_bs256_captions_per_sec": round(256 / tb, 0)}
+            rnn.train()
+        except Exception as e:
+            secondary = {"error": repr(e)}
     if world > 1:
         torch.distributed.barrier()
 
@@ -158,7 +189,7 @@ def main():
                           "batch_per_gpu": B, "global_batch": B * world, "image": "3x224x224",
                           "tokens_per_batch": int(sum(lens)), "parallelism": "dp%d" % world,
                           "final_loss": round(final_loss, 4)},
-               "roofline": roof}
+               "roofline": roof, "secondary": secondary}
         if world == 1 and not a.no_cpu_baseline:
             cores = min(os.cpu_count() or 1, 16)
             try:
