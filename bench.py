@@ -83,9 +83,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
-    rank, world, local = parallel.init_from_env("nccl")
+    ndev = torch.cuda.device_count()
+    # RCCL (backend "nccl") is the product path; SHOWTELL_DIST_BACKEND=gloo only exists to rehearse N>1 on a 1-GPU box
+    backend = os.environ.get("SHOWTELL_DIST_BACKEND", "nccl")
+    rank, world, local = parallel.init_from_env(backend, device_index=(int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16
@@ -126,10 +130,11 @@ def main():
     roof = None
     if rank == 0:
         lib().st_prof_enable(1)
-        for _ in range(max(1, a.profile_steps)):
-            trainer.step(image, caption, lens)
-        trainer.flush()
-        torch.cuda.synchronize()
+    for _ in range(max(1, a.profile_steps)):           # every rank steps: the gradient all-reduce is collective
+        trainer.step(image, caption, lens)
+    trainer.flush()
+    torch.cuda.synchronize()
+    if rank == 0:
         ms, fl, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_long * 8)()
         lib().st_prof_collect(ms, fl, n)
         lib().st_prof_enable(0)

@@ -20,7 +20,7 @@ import torch.distributed as dist
 BUCKET_ELEMS = 8 * 1024 * 1024   # 32 MB fp32 per message: large enough to run at link bandwidth
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, device_index=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
@@ -28,8 +28,8 @@ def init_from_env(backend=None):
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local if device_index is None else device_index)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
