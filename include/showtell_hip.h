@@ -69,7 +69,7 @@ int st_conv(const st_conv_desc* d, void* stream);
 /* Launch profiler for bench.py's roofline: HIP events around every st_conv launch on its stream.
  * st_prof_collect fills 8-entry arrays indexed by kernel variant (0: bf16 128x128 tile,
  * 1: bf16 128x64, 2: bf16 64x128, 4..6 the same for f32); synchronise the device first. */
-int st_tune(int ring, int kc, int w8);   /* main-loop variant knobs for tools/bench_conv.py; -1 = keep */
+int st_tune(int reserved, int kc, int w8);   /* main-loop variant knobs for tools/bench_conv.py (row chunk count 4|8, block shape); -1 = keep */
 int st_prof_enable(int on);
 int st_prof_collect(double* ms, double* flops, long* launches);
 

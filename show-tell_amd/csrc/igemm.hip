@@ -67,8 +67,8 @@ template <> struct Mfma<float> {
 
 // ---- epilogue shared by both main loops ---------------------------------------------------------
 // On entry every wave has passed a barrier after its last LDS read of the K loop and no LDS-DMA is in flight.
-// RAWB: barriers are raw s_barrier + lgkmcnt(0) (an LDS-DMA ring may be in flight: __syncthreads() would drain it);
-// only waves [SW0, SW0+SNW) touch global memory (their vmcnt then never mixes with the DMA waves' counted waits).
+// RAWB: barriers are raw s_barrier + lgkmcnt(0) (for main loops that keep LDS-DMA in flight: __syncthreads() would
+// drain it); only waves [SW0, SW0+SNW) touch global memory.  The production main loop uses the defaults.
 template <bool RAWB> __device__ __forceinline__ void epi_barrier() {
   if (RAWB) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -391,324 +391,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
 }
 
-// =======================================================================================
-// Main loop 2: LDS-DMA ring.  global_load_lds (16 B per lane, 1 KiB per wave-instruction) writes the
-// K-tiles straight into a ring of NS LDS stages, NS-1 tiles ahead of the MFMAs; a tile is waited for
-// with a COUNTED s_waitcnt vmcnt (never 0 inside the loop) and one raw s_barrier per K-tile.
-// The LDS image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE chunk and to the
-// reads (cdna_hip_programming.md rule 21).  Padding / ragged lanes read a 16-byte zero word instead.
-// One 4-wave block per CU (NS x 32 KiB of LDS): latency is hidden by the ring, not by occupancy.
-// =======================================================================================
-__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
-
-typedef const void __attribute__((address_space(1))) * gptr_t;
-typedef void __attribute__((address_space(3))) * lptr_t;
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool FAST>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_ring_kernel(IgemmArgs a) {
-  constexpr int NT = 64 * WM * WN, NW = WM * WN;
-  constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int BK = 8 * EPC;
-  constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);     // 1-KiB pieces (8 rows) per wave per tile
-  constexpr int G = PA + PB;                                // LDS-DMA instructions per wave per tile
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr int TILE_BYTES = (BM + BN) * 128;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/loader mismatch");
-  static_assert((NS - 1) * G <= 63, "vmcnt range");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int nblk = a.nbm * a.nbn;
-  int lid;
-  {
-    const int id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-  }
-  const int bm = lid / a.nbn, bn = lid - bm * a.nbn;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid - wm * WN;
-
-  // lane -> (row inside an 8-row piece, source chunk); LDS slot lane&7 of that row receives chunk ccol
-  const int prow = lane >> 3, ccol = (lane & 7) ^ prow;
-  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
-  const T* Z = reinterpret_cast<const T*>(g_zero16);
-  int pixbase[PA], hw0[PA];
-  const T* arow[PA];
-  unsigned long long amask[PA];
-  const int HoWo = a.Ho * a.Wo;
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int m = bm * BM + (wid + NW * i) * 8 + prow;
-    pixbase[i] = 0; hw0[i] = (int)0x80008000; arow[i] = X; amask[i] = 0ull;
-    if (m < a.M) {
-      const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
-      const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
-      pixbase[i] = b * a.Hin * a.Win;
-      hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
-      if (FAST) {
-        arow[i] = X + ((long)(pixbase[i] + hi0 * a.Win + wi0) * a.ldx + ccol * EPC);
-        for (int fh = 0; fh < a.KH; ++fh)
-          for (int fw = 0; fw < a.KW; ++fw)
-            if ((unsigned)(hi0 + fh) < (unsigned)a.Hin && (unsigned)(wi0 + fw) < (unsigned)a.Win)
-              amask[i] |= 1ull << (fh * a.KW + fw);
-      }
-    }
-  }
-  const T* wptr[PB];
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int n = bn * BN + (wid + NW * i) * 8 + prow;
-    wptr[i] = n < a.N ? W + ((long)n * a.ldw + ccol * EPC) : nullptr;
-  }
-  int kc = FAST ? 0 : ccol * EPC, kh = 0, kw = 0, tap = 0;
-  long tapoff = 0;
-  if (!FAST) while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
-  int klin = 0;
-  const int ntap = a.KH * a.KW;
-
-  auto issue = [&](int stage) {
-    char* base = smem + stage * TILE_BYTES;
-    const bool kok = FAST ? (a.korder ? kc < a.Cin : tap < ntap) : kh < a.KH;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const T* src = Z;
-      if (FAST) {
-        const T* cand = arow[i] + (tapoff + kc);
-        src = (kok && ((amask[i] >> tap) & 1ull)) ? cand : Z;
-      } else {
-        const int hi = (hw0[i] >> 16) + kh, wi = (int)(short)(hw0[i] & 0xffff) + kw;
-        const bool ok = kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
-        src = ok ? X + ((long)(pixbase[i] + hi * a.Win + wi) * a.ldx + kc) : Z;
-      }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (wid + NW * i) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const T* src = (kok && wptr[i]) ? wptr[i] + klin : Z;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + BM * 128 + (wid + NW * i) * 1024), 16, 0, 0);
-    }
-    klin += BK;
-    kc += BK;
-    if (FAST) {
-      if (a.korder) {   // channel chunk outer, filter tap inner: the taps of one chunk re-touch the same lines (L1)
-        kc -= BK;
-        ++tap; if (++kw == a.KW) { kw = 0; ++kh; }
-        if (tap == ntap) { tap = 0; kh = 0; kw = 0; kc += BK; }
-        tapoff = (long)(kh * a.Win + kw) * a.ldx;
-      } else if (kc >= a.Cin) { kc = 0; ++tap; if (++kw == a.KW) { kw = 0; ++kh; } tapoff = (long)(kh * a.Win + kw) * a.ldx; }
-    } else {
-      while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
-    }
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int r16 = lane & 15, q4 = lane >> 4;
-  const int nk = (a.K + BK - 1) / BK;
-
-  // Software pipeline (per wave): the fragment reads of the NEXT half K-tile are in flight while the MFMAs of
-  // the current half run, so the LDS phase and the matrix phase of a wave overlap instead of alternating:
-  //   reads f1(kt) | MFMA f0(kt) | wait tile kt+1 + barrier | DMA tile kt+NS | reads f0(kt+1) | MFMA f1(kt)
-  // Tiles past the end of K are all-zero reads: they keep the DMA counts uniform.
-  auto read_frags = [&](const char* base, int ks, u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
-    const int so = ((ks * 4 + q4) ^ (r16 & 7)) << 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      fa[i] = *reinterpret_cast<const u32x4*>(base + (wm * (BM / WM) + i * 16 + r16) * 128 + so);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-      fb[j] = *reinterpret_cast<const u32x4*>(base + (BM + wn * (BN / WN) + j * 16 + r16) * 128 + so);
-  };
-  auto mma = [&](u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
-  };
-
-#pragma unroll
-  for (int s = 0; s < NS; ++s) issue(s);
-  wait_vmcnt<(NS - 1) * G>();                      // tile 0 has landed (this wave's pieces)
-  __builtin_amdgcn_s_barrier();                    // ... and everybody else's
-  u32x4 fa0[TM] = {}, fb0[TN] = {}, fa1[TM] = {}, fb1[TN] = {};
-  read_frags(smem, 0, fa0, fb0);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt % NS) * TILE_BYTES;
-    const char* nxt = smem + ((kt + 1) % NS) * TILE_BYTES;
-    read_frags(cur, 1, fa1, fb1);
-    mma(fa0, fb0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // f1(kt) is in registers: this wave is done with tile kt
-    wait_vmcnt<(NS - 2) * G>();                    // tile kt+1 has landed
-    __builtin_amdgcn_s_barrier();                  // everybody is done with tile kt; tile kt+1 is complete
-    issue(kt % NS);                                // refill the stage just released with tile kt+NS
-    read_frags(nxt, 0, fa0, fb0);
-    mma(fa1, fb1);
-  }
-  wait_vmcnt<0>();                                 // the over-issued (all-zero) tail tiles
-  __syncthreads();
-  igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
-}
-
-// =======================================================================================
-// Main loop 3: PERSISTENT LDS-DMA ring.  One 8-wave block per CU walks a list of 128x128 output tiles; the
-// K-tile stream of the ring continues ACROSS tile boundaries, so the first K-tiles of the next tile (and its
-// row set-up) are already in flight while the current tile's MFMAs and epilogue run: launch/prologue latency
-// is paid once per kernel, not once per tile.
-//   * waves 0-3 issue the DMA (8 x 1 KiB pieces per K-tile each) and own the counted vmcnt waits;
-//   * waves 4-7 do all global stores / atomics of the epilogue.  vmcnt is per wave and in order, so keeping
-//     stores out of the DMA waves keeps their counts exact; the store waves never wait on memory;
-//   * all 8 waves run the MFMAs (wave tile 64x32); epilogue barriers are raw (s_barrier + lgkmcnt(0)) and its
-//     staging buffer lives outside the ring.
-// Requires the FAST address walk (Cin % 64 == 0 for bf16).
-// =======================================================================================
-template <typename T, int NS>
-__global__ __launch_bounds__(512) void igemm_pring_kernel(IgemmArgs a) {
-  constexpr int BM = 128, BN = 128, WM = 2, WN = 4, NW = 8, NLW = 4;
-  constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int BK = 8 * EPC;
-  constexpr int PA = BM / (8 * NLW), PB = BN / (8 * NLW);
-  constexpr int G = PA + PB;
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr int TILE_BYTES = (BM + BN) * 128;
-  static_assert((NS - 1) * G <= 63, "vmcnt range");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const epi_smem = smem + NS * TILE_BYTES;
-
-  const int ntiles = a.nbm * a.nbn;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid - wm * WN;
-  const bool loader = wid < NLW;
-  const int nk = (a.K + BK - 1) / BK;
-  const int ntap = a.KH * a.KW;
-
-  auto tile_coords = [&](int t, int& bm, int& bn) {     // XCD-aware tile order (bijective)
-    const int xcd = t & 7, q = ntiles >> 3, r = ntiles & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
-    bm = lid / a.nbn; bn = lid - bm * a.nbn;
-  };
-
-  // ---- issue side (loader waves): per-tile row set-up + block-uniform tap walk ------------------------
-  const int prow = lane >> 3, ccol = (lane & 7) ^ prow;
-  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
-  const T* Z = reinterpret_cast<const T*>(g_zero16);
-  const T* arow[PA]; unsigned long long amask[PA]; const T* wptr[PB];
-  const int HoWo = a.Ho * a.Wo;
-  int it_tile = blockIdx.x, it_kt = 0;
-  int kc = 0, kh = 0, kw = 0, tap = 0, klin = 0;
-  long tapoff = 0;
-  auto setup_tile = [&](int t) {
-    int bm, bn;
-    tile_coords(t, bm, bn);
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int m = bm * BM + (wid + NLW * i) * 8 + prow;
-      arow[i] = X; amask[i] = 0ull;
-      if (m < a.M) {
-        const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
-        arow[i] = X + ((long)(b * a.Hin * a.Win + hi0 * a.Win + wi0) * a.ldx + ccol * EPC);
-        for (int fh = 0; fh < a.KH; ++fh)
-          for (int fw = 0; fw < a.KW; ++fw)
-            if ((unsigned)(hi0 + fh) < (unsigned)a.Hin && (unsigned)(wi0 + fw) < (unsigned)a.Win)
-              amask[i] |= 1ull << (fh * a.KW + fw);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int n = bn * BN + (wid + NLW * i) * 8 + prow;
-      wptr[i] = n < a.N ? W + ((long)n * a.ldw + ccol * EPC) : nullptr;
-    }
-    kc = 0; kh = 0; kw = 0; tap = 0; klin = 0; tapoff = 0;
-  };
-  auto issue = [&](int slot) {
-    if (!loader) return;
-    char* base = smem + slot * TILE_BYTES;
-    const bool live = it_tile < ntiles;
-    const bool kok = live && (a.korder ? kc < a.Cin : tap < ntap);
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const T* cand = arow[i] + (tapoff + kc);
-      const T* src = (kok && ((amask[i] >> tap) & 1ull)) ? cand : Z;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (wid + NLW * i) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const T* src = (kok && wptr[i]) ? wptr[i] + klin : Z;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + BM * 128 + (wid + NLW * i) * 1024), 16, 0, 0);
-    }
-    if (!live) return;
-    klin += BK;
-    if (a.korder) {
-      ++tap; if (++kw == a.KW) { kw = 0; ++kh; }
-      if (tap == ntap) { tap = 0; kh = 0; kw = 0; kc += BK; }
-      tapoff = (long)(kh * a.Win + kw) * a.ldx;
-    } else {
-      kc += BK;
-      if (kc >= a.Cin) { kc = 0; ++tap; if (++kw == a.KW) { kw = 0; ++kh; } tapoff = (long)(kh * a.Win + kw) * a.ldx; }
-    }
-    if (++it_kt == nk) {                                // next K-tile belongs to the block's next output tile
-      it_kt = 0;
-      it_tile += gridDim.x;
-      if (it_tile < ntiles) setup_tile(it_tile);
-    }
-  };
-
-  if (loader && it_tile < ntiles) setup_tile(it_tile);
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s);
-
-  const int r16 = lane & 15, q4 = lane >> 4;
-  int g = 0;                                            // K-tiles consumed by this block so far
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nk; ++kt, ++g) {
-      if (loader) wait_vmcnt<(NS - 2) * G>();           // K-tile g has landed (this wave's pieces)
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();                     // ... everybody's; the slot of K-tile g-1 is free
-      asm volatile("" ::: "memory");
-      issue((g + NS - 1) % NS);
-      const char* base = smem + (g % NS) * TILE_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int so = ((ks * 4 + q4) ^ (r16 & 7)) << 4;
-        u32x4 fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const u32x4*>(base + (wm * (BM / WM) + i * 16 + r16) * 128 + so);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const u32x4*>(base + (BM + wn * (BN / WN) + j * 16 + r16) * 128 + so);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
-      }
-    }
-    int bm, bn;
-    tile_coords(tile, bm, bn);
-    igemm_epilogue<T, BM, BN, WM, WN, true, NLW, NW - NLW>(a, acc, epi_smem, bm, bn, tid);
-  }
-  if (loader) wait_vmcnt<0>();                          // over-issued all-zero K-tiles
-}
-
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool FAST>
 int launch_(IgemmArgs& a, hipStream_t st) {
   a.nbm = (a.M + BM - 1) / BM;
@@ -747,86 +429,11 @@ int launch(IgemmArgs& a, hipStream_t st) {
   return fast ? launch_<T, BM, BN, WM, WN, KC, true>(a, st) : launch_<T, BM, BN, WM, WN, KC, false>(a, st);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool FAST>
-int launch_ring_(IgemmArgs& a, hipStream_t st) {
-  a.nbm = (a.M + BM - 1) / BM;
-  a.nbn = (a.N + BN - 1) / BN;
-  constexpr int lds = NS * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<T, BM, BN, WM, WN, NS, FAST>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + 3;
-  ProfRec rec; bool prof = false;
-  if (g_prof_on) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_prof.size() < kProfMax && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
-      rec.variant = variant; rec.flops = a.flops; prof = true;
-      (void)hipEventRecord(rec.e0, st);
-    }
-  }
-  hipLaunchKernelGGL((igemm_ring_kernel<T, BM, BN, WM, WN, NS, FAST>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
-  if (prof) {
-    (void)hipEventRecord(rec.e1, st);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back(rec);
-  }
-  ST_LAUNCH_CHECK();
-  return 0;
-}
-
-template <typename T, int NS>
-int launch_pring(IgemmArgs& a, hipStream_t st) {
-  a.nbm = (a.M + 127) / 128;
-  a.nbn = (a.N + 127) / 128;
-  constexpr int lds = NS * 256 * 128 + 64 * (128 + 4) * 4 + 256;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pring_kernel<T, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-  }
-  const int ntiles = a.nbm * a.nbn;
-  const int grid = ntiles < ncu ? ntiles : ncu;
-  constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + 3;
-  ProfRec rec; bool prof = false;
-  if (g_prof_on) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_prof.size() < kProfMax && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
-      rec.variant = variant; rec.flops = a.flops; prof = true;
-      (void)hipEventRecord(rec.e0, st);
-    }
-  }
-  hipLaunchKernelGGL((igemm_pring_kernel<T, NS>), dim3(grid), dim3(512), lds, st, a);
-  if (prof) {
-    (void)hipEventRecord(rec.e1, st);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back(rec);
-  }
-  ST_LAUNCH_CHECK();
-  return 0;
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int NS>
-int launch_ring(IgemmArgs& a, hipStream_t st) {
-  constexpr int BK = 8 * (16 / (int)sizeof(T));
-  const bool fast = (a.Cin % BK == 0) && a.KH * a.KW <= 64;
-  return fast ? launch_ring_<T, BM, BN, WM, WN, NS, true>(a, st) : launch_ring_<T, BM, BN, WM, WN, NS, false>(a, st);
-}
-
-int g_tune[3] = {-1, -1, -1};   // ring, kc, w8 (-1: take the environment default)
+int g_tune[3] = {-1, -1, -1};   // (unused), kc, w8 (-1: take the environment default)
 int tuning_get(int i, const char* env) {
   if (g_tune[i] < 0) { const char* e = getenv(env); g_tune[i] = e ? atoi(e) : 0; }
   return g_tune[i];
 }
-int tuning_ring() { return tuning_get(0, "ST_IGEMM_RING"); }
 
 int tuning_w8() { if (g_tune[2] < 0) { const char* e = getenv("ST_IGEMM_W8"); g_tune[2] = e ? atoi(e) : 1; } return g_tune[2]; }
 int tuning_kc() { return tuning_get(1, "ST_IGEMM_KC"); }
@@ -845,17 +452,6 @@ int dispatch_kc(IgemmArgs& a, hipStream_t st) {
 
 template <typename T>
 int dispatch(IgemmArgs& a, hipStream_t st) {
-  const int ring = tuning_ring();
-  if (ring == 3 && a.N > 64) return launch_ring<T, 128, 128, 2, 2, 3>(a, st);
-  if (ring == 4 && a.N > 64) return launch_ring<T, 128, 128, 2, 2, 4>(a, st);
-  if (ring == 13 && a.N > 64) return launch_ring<T, 128, 128, 2, 4, 3>(a, st);
-  if (ring == 14 && a.N > 64) return launch_ring<T, 128, 128, 2, 4, 4>(a, st);
-  if (ring == 23 && a.N > 64) return launch_ring<T, 256, 128, 4, 2, 3>(a, st);
-  {
-    constexpr int BK = 8 * (16 / (int)sizeof(T));
-    const bool fast = (a.Cin % BK == 0) && a.KH * a.KW <= 64;
-    if (ring == 33 && a.N > 64 && fast) return launch_pring<T, 3>(a, st);
-  }
   const int kc = tuning_kc();
   if (kc == 4 && !a.korder) return dispatch_kc<T, 4>(a, st);
   return dispatch_kc<T, 8>(a, st);

@@ -10,7 +10,7 @@ SHAPES = [  # cin, cout, k, s, hin
     (256, 256, 3, 1, 14), (256, 1024, 1, 1, 14), (1024, 256, 1, 1, 14), (64, 256, 1, 1, 56),
     (128, 512, 1, 1, 28), (64, 64, 3, 1, 56), (128, 128, 3, 1, 28), (512, 512, 3, 1, 7), (512, 2048, 1, 1, 7),
 ]
-VARIANTS = [("t256x128", 0, 8, 2), ("base kc8 4w", 0, 8, 0), ("base kc8 8w", 0, 8, 1), ("base kc4 8w", 0, 4, 1), ("ring3", 3, 8, 0), ("ring4", 4, 8, 0), ("ring3w8", 13, 8, 0), ("ring4w8", 14, 8, 0), ("ring3_256", 23, 8, 0), ("pring3", 33, 8, 0)]
+VARIANTS = [("kc8 4w", 0, 8, 0), ("kc8 8w", 0, 8, 1), ("kc4 8w", 0, 4, 1), ("256x128", 0, 8, 2)]
 if len(sys.argv) > 1:
     VARIANTS = [v for v in VARIANTS if any(v[0].startswith(a) for a in sys.argv[1:])]
 dt = torch.bfloat16
