@@ -36,6 +36,10 @@ CONV_CASES = [
     (1, 7, 7, 512, 2048, 1, 1, 0),
     (2, 32, 32, 8, 64, 7, 2, 3),     # stem geometry, channels padded 3 -> 8
     (1, 9, 11, 16, 24, 3, 1, 1),     # ragged everything
+    (3, 28, 28, 128, 128, 3, 1, 1),  # layer2 3x3
+    (2, 56, 56, 64, 64, 3, 1, 1),    # layer1 3x3, 64-channel tile
+    (5, 7, 7, 512, 512, 3, 1, 1),    # layer4 3x3, ragged batch
+    (200, 7, 7, 64, 256, 3, 1, 1),   # many small images
 ]
 
 
@@ -180,6 +184,24 @@ def test_layout_and_pool_kernels(dtype):
     assert float(tt[:, 77:].float().abs().max()) == 0.0
     c = ops.cast(t, torch.float32)
     assert torch.equal(c.cpu(), t.float().cpu())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3x3_eval_epilogue_chunk_major_weights(dtype):
+    """3x3 conv, chunk-major weights, folded-BN + residual + ReLU epilogue (BasicBlock conv2 in eval mode)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    B, H, Cc = 3, 14, 64
+    x = torch.randn(B, Cc, H, H, generator=g)
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) / 24
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    res = torch.randn(B, H, H, Cc, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, res = x.bfloat16().float(), w.bfloat16().float(), res.bfloat16().float()
+    ref = F.relu(F.conv2d(x, w, None, 1, 1).permute(0, 2, 3, 1) * sc + sh + res)
+    y = ops.conv_nhwc(x.permute(0, 2, 3, 1).contiguous().to("cuda", dtype), ops.pack_conv_weight(w.cuda(), dtype, k_order=1),
+                      3, 3, 1, 1, scale=sc.cuda(), shift=sh.cuda(), residual=res.to("cuda", dtype), relu=True, k_order=1)
+    _close(y, ref, dtype, "3x3 folded-BN epilogue")
 
 
 def test_bad_arguments_fail_loudly():
