@@ -171,7 +171,37 @@ def main():
             torch.cuda.synchronize(); tb = time.perf_counter()
             rnn.beam_search(f256, 5, 1, 25)
             torch.cuda.synchronize(); tb = time.perf_counter() - tb
-            secondary = {"greedy_decode_us_per_step": round(us_step, 1), "greedy_algorithmic_MB_per_step": round(byts / 1e6, 2),
+            # Config 5 quality check: beam=5 captions of the HIP path vs the CPU oracle (beam_search.py semantics) on the
+            # same weights, 8 images.  The fp32 kernels must reproduce the oracle's token ids (BLEU-4 = 1); the bf16 id-match
+            # rate is reported beside it (random-init weights make near-ties common, so bf16 rounding flips some beams).
+            from oracle import restatement as R
+            sd = R.init_decoder_params(E, H, V, L, "gru", seed=6)               # the seeded weights of tests/test_gpu_beam.py
+            sd["linear.weight"] *= 12.0; sd["linear.bias"][2] += 1.5           # sharpen so that <end> competes
+            r32 = RNN(E, H, V, L, dtype=torch.float32); r32.load_state_dict(sd); r32 = r32.to(dev).eval()
+            r16 = RNN(E, H, V, L, dtype=torch.bfloat16); r16.load_state_dict(sd); r16 = r16.to(dev).eval()
+            fq = torch.randn(12, E, generator=torch.Generator().manual_seed(6))
+            h32, h16 = r32.beam_search(fq.to(dev), 5, 1, 25), r16.beam_search(fq.to(dev), 5, 1, 25)
+            gts, res, same16, same32, nonempty = {}, {}, 0, 0, 0
+            for b in range(12):
+                init, gen = R.gru_beam_callbacks(sd, fq[b])
+                with torch.no_grad():
+                    ref = R.beam_search(init, gen, [0], 1, 2, beam_width=5, num_hypotheses=1, max_length=25)
+                ref_seq = ref[0].to_sequence_of_values() if ref else []
+                nonempty += int(bool(ref_seq))
+                same32 += int((h32[b][0][0] if h32[b] else []) == ref_seq)
+                same16 += int((h16[b][0][0] if h16[b] else []) == ref_seq)
+            # BLEU-4 needs long captions: 25-token greedy captions, bf16 HIP vs fp32 oracle (rnn.py:37-58)
+            with torch.no_grad():
+                g_ref = R.rnn_greedy(sd, fq[:8])
+            g_hip = r16.sentence_index(fq[:8].to(dev)).cpu()
+            for b in range(8):
+                gts[str(b)] = [" ".join(map(str, g_ref[b].tolist()))]
+                res[str(b)] = [" ".join(map(str, g_hip[b].tolist()))]
+            bleu4 = R.bleu_corpus(gts, res, 4)[3]
+            del r32, r16
+            secondary = {"greedy_decode_us_per_step": round(us_step, 1), "beam5_fp32_id_match_12img": round(same32 / 12.0, 3), "beam5_bf16_id_match_12img": round(same16 / 12.0, 3),
+                         "greedy_bf16_bleu4_vs_fp32_oracle_8img": round(float(bleu4), 4),
+                         "beam5_oracle_nonempty_12img": nonempty, "greedy_algorithmic_MB_per_step": round(byts / 1e6, 2),
                          "greedy_hbm_roofline": {"bound": "hbm", "achieved": round(byts / us_step / 1e3, 1), "peak": 8000.0,
                                                  "unit": "GB/s", "frac": round(byts / us_step / 1e3 / 8000.0, 4)},
                          "greedy_captions_per_sec": round(B / (us_step * 25e-6), 0),
