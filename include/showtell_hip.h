@@ -39,11 +39,16 @@ int st_version(void);
 /* ------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / dense projection on MFMA.
  *   y[m][n] = sum_k x_gather[m][k] * w[n][k]        m = (b,ho,wo), k = (kh,kw,c)
+ * Sliding-window form: KW == 1, pad == 0 and ldx < Cin with Cin % ldx == 0 reads Cin consecutive elements
+ * starting at pixel (hi, wi), i.e. Cin/ldx neighbouring pixels of one row as one tap (the space-to-depth
+ * stem); the caller's rows must be wide enough: (Wo-1)*stride + Cin/ldx <= Win.
  * Replaces: torchvision conv2d inside cnn.py:46 / cnn_attn.py:46 (cuDNN conv),
  * nn.Linear at cnn.py:49, rnn.py:33 and the GRU input projections inside rnn.py:32.
  * A plain GEMM is the case KH=KW=1, Hin=Win=Ho=Wo=1, B=M, Cin=K.
  * Epilogue (all optional, in this order):  v = acc + bias[n];  stats[n] += v, stats[N+n] += v*v
- * (fp32 atomics, batch-norm statistics);  v = v*scale[n] + shift[n];  v += residual[m][n];
+ * (fp32 atomics, batch-norm statistics; with stats_replicas = R > 1 the buffer is [R][2N] and pixel tile t
+ * adds into replica t % R -- same-address float atomics serialise at the memory side, ~25 ns each, so layers
+ * with thousands of pixel tiles spread them; the consumer sums the replicas);  v = v*scale[n] + shift[n];  v += residual[m][n];
  * v = max(v,0) if relu;  y = (accumulate ? y : 0) + v.
  * Requirements: Cin, ldx, ldw multiples of 8 (bf16) / 4 (f32); ldy multiple of 4.
  * ---------------------------------------------------------------------------------- */
@@ -62,6 +67,7 @@ typedef struct {
   int relu, accumulate;
   int Cin_logical;      /* 0 = Cin; the un-padded channel count (profiler FLOP accounting) */
   int k_order;          /* 0: w is [N][KH][KW][Cin]; 1: w is [N][Cin/CH][KH][KW][CH], CH = 128 bytes of channels */
+  int stats_replicas;   /* 0/1: stats is [2N]; R > 1: stats is [R][2N] (see above)               */
 } st_conv_desc;
 
 int st_conv(const st_conv_desc* d, void* stream);
@@ -89,6 +95,7 @@ typedef struct {
   const float* res_running_mean; const float* res_running_var;
   int res_bn;          /* 1: residual goes through its own BN (downsample branch)   */
   int dtype; long rows; int C; float count; float eps; int relu;
+  int stats_replicas, res_stats_replicas;   /* 0/1: [2C]; R > 1: [R][2C], summed here (st_conv_desc.stats_replicas) */
 } st_bn_act_desc;
 
 int st_bn_act(const st_bn_act_desc* d, void* stream);
@@ -99,10 +106,22 @@ int st_bn_update_running(const float* stats, float* running_mean, float* running
 
 /* NCHW fp32 images (utils.py:61-77 layout) -> NHWC dtype with channels zero-padded to Cpad */
 int st_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cpad, void* stream);
+/* NCHW fp32 RGB images (even H, W) -> 2x2 space-to-depth NHWC [B][H/2+3][W/2+3][16] dtype: blocked pixel (p,q) holds
+ * rows 2(p-2)+dy, cols 2(q-2)+dx as channel (dy*2+dx)*3+c; channels 12..15 and the border (2 before, 1 after) are zero.
+ * With st_stem_weight_s2d the torchvision stem (7x7 s2 p3, cnn.py:46) becomes st_conv's sliding-window form:
+ * Hin=H/2+3, Win=W/2+3, Cin=64, ldx=16, KH=4, KW=1, stride=1, pad=0, Ho=H/2, Wo=W/2, ldw=256. */
+int st_nchw_to_s2d16(const float* x, void* y, int dtype, int B, int H, int W, void* stream);
+/* packed stem weights [64][7][7][Cpad] dtype (st_pack_conv_weight, k_order 0) -> [64][4][4][16] dtype for the blocked image */
+int st_stem_weight_s2d(const void* w, void* out, int dtype, int Cpad, void* stream);
 /* NHWC dtype -> (B,C,H*W) fp32, the layout cnn_attn.py:49 returns */
 int st_nhwc_to_ncp_f32(const void* x, float* y, int dtype, int B, int HW, int C, void* stream);
 /* 3x3 stride-2 pad-1 max pool NHWC (torchvision resnet maxpool, cnn.py:46) */
 int st_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream);
+/* y = maxpool3x3s2(relu(batchnorm(x))): the stem's bn1 + relu + maxpool of torchvision's resnet in one pass
+ * (train: stats = [sum|sumsq] over `count` rows; eval: stats NULL, running buffers).  C must divide 2048 (bf16) / 1024 (f32). */
+int st_maxpool3x3s2_bn(const void* x, void* y, int dtype, int B, int H, int W, int C,
+                       const float* stats, const float* gamma, const float* beta,
+                       const float* running_mean, const float* running_var, float count, float eps, void* stream);
 /* global average pool NHWC -> [B][C] (adaptive avgpool, cnn.py:34) */
 int st_global_avgpool(const void* x, void* y, int dtype, int out_dtype, int B, int HW, int C, void* stream);
 

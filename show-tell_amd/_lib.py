@@ -19,14 +19,15 @@ class ConvDesc(C.Structure):
                 ("residual", c_p), ("stats", c_p), ("dtype", c_i), ("out_dtype", c_i),
                 ("B", c_i), ("Hin", c_i), ("Win", c_i), ("Cin", c_i), ("Ho", c_i), ("Wo", c_i), ("N", c_i),
                 ("KH", c_i), ("KW", c_i), ("stride", c_i), ("pad", c_i),
-                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i), ("Cin_logical", c_i), ("k_order", c_i)]
+                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i), ("Cin_logical", c_i), ("k_order", c_i), ("stats_replicas", c_i)]
 
 
 class BnActDesc(C.Structure):
     _fields_ = [("x", c_p), ("y", c_p), ("res", c_p), ("stats", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("res_stats", c_p), ("res_gamma", c_p),
                 ("res_beta", c_p), ("res_running_mean", c_p), ("res_running_var", c_p), ("res_bn", c_i),
-                ("dtype", c_i), ("rows", c_l), ("C", c_i), ("count", c_f), ("eps", c_f), ("relu", c_i)]
+                ("dtype", c_i), ("rows", c_l), ("C", c_i), ("count", c_f), ("eps", c_f), ("relu", c_i),
+                ("stats_replicas", c_i), ("res_stats_replicas", c_i)]
 
 
 ST_MAX_LAYERS = 8
@@ -68,8 +69,11 @@ _SIGS = {
     "st_bn_act": ([C.POINTER(BnActDesc), c_p], c_i),
     "st_bn_update_running": ([c_p, c_p, c_p, c_i, c_f, c_f, c_p], c_i),
     "st_nchw_to_nhwc": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_nchw_to_s2d16": ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_stem_weight_s2d": ([c_p, c_p, c_i, c_i, c_p], c_i),
     "st_nhwc_to_ncp_f32": ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_maxpool3x3s2": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_maxpool3x3s2_bn": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p], c_i),
     "st_global_avgpool": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_cast": ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
     "st_transpose": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),

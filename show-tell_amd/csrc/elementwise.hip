@@ -1,6 +1,7 @@
 // HBM-bound elementwise / layout kernels of the encoder path (gfx950).
 // Every kernel moves 16 bytes per lane per access and grid-strides over a capped grid.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -40,13 +41,15 @@ template <> struct Vec<float> {
 // ---------------------------------------------------------------------------------------
 // batch-norm apply (+ residual [+ its own BN]) (+ ReLU)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void bn_coeff(const float* stats, const float* gamma, const float* beta,
+__device__ __forceinline__ void bn_coeff(const float* stats, int reps, const float* gamma, const float* beta,
                                          const float* rmean, const float* rvar, int C, int c,
                                          float inv_count, float eps, float& sc, float& sh) {
   float mean, var;
   if (stats) {
-    mean = stats[c] * inv_count;
-    var = fmaxf(stats[C + c] * inv_count - mean * mean, 0.f);
+    float s = stats[c], ss = stats[C + c];
+    for (int r = 1; r < reps; ++r) { s += stats[(size_t)r * 2 * C + c]; ss += stats[(size_t)r * 2 * C + C + c]; }
+    mean = s * inv_count;
+    var = fmaxf(ss * inv_count - mean * mean, 0.f);
   } else {
     mean = rmean[c]; var = rvar[c];
   }
@@ -61,10 +64,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(st_bn_act_desc d) {
   const float inv = 1.0f / d.count;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sc, sh;
-    bn_coeff(d.stats, d.gamma, d.beta, d.running_mean, d.running_var, C, c, inv, d.eps, sc, sh);
+    bn_coeff(d.stats, d.stats_replicas, d.gamma, d.beta, d.running_mean, d.running_var, C, c, inv, d.eps, sc, sh);
     coef[c] = sc; coef[C + c] = sh;
     if (d.res_bn) {
-      bn_coeff(d.res_stats, d.res_gamma, d.res_beta, d.res_running_mean, d.res_running_var, C, c, inv, d.eps, sc, sh);
+      bn_coeff(d.res_stats, d.res_stats_replicas, d.res_gamma, d.res_beta, d.res_running_mean, d.res_running_var, C, c, inv, d.eps, sc, sh);
       coef[2 * C + c] = sc; coef[3 * C + c] = sh;
     }
   }
@@ -100,6 +103,76 @@ __global__ __launch_bounds__(256) void bn_act_kernel(st_bn_act_desc d) {
   }
 }
 
+// Register-coefficient form for the common case blockDim*N % C == 0 (C a power of two <= 2048): a thread keeps
+// the same N channels for the whole grid-stride loop, so it loads only its own coefficients (four 32-byte reads
+// issued together with the first data load) -- no LDS table, no barrier, no per-block pass over all C channels.
+// The small 14x14 / 7x7 tensors are latency-bound, and that preamble was most of their time.
+template <int N> __device__ __forceinline__ void ldf(const float* p, float* f) {
+#pragma unroll
+  for (int i = 0; i < N; i += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+    f[i] = v[0]; f[i + 1] = v[1]; f[i + 2] = v[2]; f[i + 3] = v[3];
+  }
+}
+template <int N> __device__ __forceinline__ void bn_coeff_vec(const float* stats, const float* gamma, const float* beta,
+                                                               const float* rmean, const float* rvar, int C, int c,
+                                                               float inv_count, float eps, float* sc, float* sh) {
+  float a[N], b[N], g[N], be[N];
+  ldf<N>(stats ? stats + c : rmean + c, a);
+  ldf<N>(stats ? stats + C + c : rvar + c, b);
+  ldf<N>(gamma + c, g);
+  ldf<N>(beta + c, be);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float mean = stats ? a[k] * inv_count : a[k];
+    const float var = stats ? fmaxf(b[k] * inv_count - mean * mean, 0.f) : b[k];
+    sc[k] = g[k] * rsqrtf(var + eps);
+    sh[k] = be[k] - mean * sc[k];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_reg_kernel(st_bn_act_desc d) {
+  constexpr int N = Vec<T>::N;
+  const int C = d.C;
+  const int c = (threadIdx.x * N) % C;
+  const float inv = 1.0f / d.count;
+  const long nchunk = d.rows * C / N;
+  const T* x = reinterpret_cast<const T*>(d.x);
+  const T* r = reinterpret_cast<const T*>(d.res);
+  T* y = reinterpret_cast<T*>(d.y);
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float v[N], rv[N];
+  if (i < nchunk) { Vec<T>::load(x + i * N, v); if (r) Vec<T>::load(r + i * N, rv); }
+  float sc[N], sh[N], rsc[N], rsh[N];
+  bn_coeff_vec<N>(d.stats, d.gamma, d.beta, d.running_mean, d.running_var, C, c, inv, d.eps, sc, sh);
+  if (d.res_bn) bn_coeff_vec<N>(d.res_stats, d.res_gamma, d.res_beta, d.res_running_mean, d.res_running_var, C, c, inv, d.eps, rsc, rsh);
+  for (; i < nchunk; i += stride) {
+    float nv[N], nrv[N];
+    const long nx = i + stride;
+    if (nx < nchunk) { Vec<T>::load(x + nx * N, nv); if (r) Vec<T>::load(r + nx * N, nrv); }
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = v[k] * sc[k] + sh[k];
+    if (r) {
+      if (d.res_bn) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += rv[k] * rsc[k] + rsh[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += rv[k];
+      }
+    }
+    if (d.relu) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    Vec<T>::store(y + i * N, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) { v[k] = nv[k]; rv[k] = nrv[k]; }
+  }
+}
+
 __global__ void bn_update_running_kernel(const float* stats, float* rm, float* rv, int C, float count, float mom) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -113,6 +186,50 @@ __global__ void bn_update_running_kernel(const float* stats, float* rm, float* r
 // ---------------------------------------------------------------------------------------
 // layout
 // ---------------------------------------------------------------------------------------
+// fp32 NCHW (3 channels, even H and W) -> 2x2 space-to-depth NHWC [B][H/2+3][W/2+3][16]: blocked pixel (p,q) holds
+// input rows 2(p-2)+dy, cols 2(q-2)+dx as channel (dy*2+dx)*3+c; channels 12..15 and the border (2 before, 1 after)
+// are zero.  One lane per blocked pixel: 6 coalesced 8-byte reads, 32 (bf16) / 64 (f32) contiguous bytes written.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_s2d_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int H, int W) {
+  const int Hp = H / 2 + 3, Wp = W / 2 + 3;
+  const long npix = (long)B * Hp * Wp;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const long b = p / ((long)Hp * Wp);
+    const int rem = (int)(p - b * Hp * Wp), py = rem / Wp, px = rem - py * Wp;
+    const int r = py - 2, q = px - 2;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = 0.f;
+    if (r >= 0 && r < H / 2 && q >= 0 && q < W / 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const float2 t = *reinterpret_cast<const float2*>(x + ((b * 3 + c) * H + 2 * r + dy) * W + 2 * q);
+          v[(dy * 2 + 0) * 3 + c] = t.x;
+          v[(dy * 2 + 1) * 3 + c] = t.y;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 16; o += Vec<T>::N) Vec<T>::store(y + p * 16 + o, v + o);
+  }
+}
+
+// packed stem weights [64][7][7][Cpad] -> [64][4][4][16] for the blocked image: tap (i,j), channel (dy*2+dx)*3+c takes
+// the 7x7 weight at (2i+dy-1, 2j+dx-1) when that lies inside the filter, else zero.
+template <typename T>
+__global__ void stem_weight_s2d_kernel(const T* __restrict__ w, T* __restrict__ out, int Cpad) {
+  const int n = blockIdx.x, t = threadIdx.x;        // 256 threads = 4*4*16 outputs of one filter
+  const int i = t >> 6, j = (t >> 4) & 3, ch = t & 15;
+  T v = from_f32<T>(0.f);
+  if (ch < 12) {
+    const int blk = ch / 3, c = ch - blk * 3, dy = blk >> 1, dx = blk & 1;
+    const int ky = 2 * i + dy - 1, kx = 2 * j + dx - 1;
+    if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) v = w[((n * 7 + ky) * 7 + kx) * Cpad + c];
+  }
+  out[n * 256 + t] = v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y,
                                                             int B, int C, int HW, int Cpad) {
@@ -146,12 +263,19 @@ __global__ __launch_bounds__(256) void nhwc_to_ncp_kernel(const T* __restrict__ 
   }
 }
 
+struct BnArgs { int on; const float* stats; const float* gamma; const float* beta; const float* rmean; const float* rvar; float inv_count, eps; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                       int B, int H, int W, int C, int Ho, int Wo) {
+                                                       int B, int H, int W, int C, int Ho, int Wo, BnArgs bn) {
+  // bn.on: y = maxpool(relu(batchnorm(x))) -- the stem's normalise pass folded into the pool (relu and the rounding to
+  // T are monotone, so max-then-relu-then-round equals the two-pass result bit for bit).  Needs blockDim*N % C == 0:
+  // a thread keeps its N channels, coefficients live in registers.
   constexpr int N = Vec<T>::N;
   const int cv = C / N;
   const long total = (long)B * Ho * Wo * cv;
+  float sc[N], sh[N];
+  if (bn.on) bn_coeff_vec<N>(bn.stats, bn.gamma, bn.beta, bn.rmean, bn.rvar, C, (int)((threadIdx.x * N) % C), bn.inv_count, bn.eps, sc, sh);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv) * N;
     long p = i / cv;
@@ -169,9 +293,17 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
         if ((unsigned)wi >= (unsigned)W) continue;
         float v[N];
         Vec<T>::load(x + ((b * H + hi) * W + wi) * C + c, v);
+        if (bn.on) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) v[k] = v[k] * sc[k] + sh[k];
+        }
 #pragma unroll
         for (int k = 0; k < N; ++k) m[k] = fmaxf(m[k], v[k]);
       }
+    }
+    if (bn.on) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) m[k] = fmaxf(m[k], 0.f);
     }
     Vec<T>::store(y + ((b * Ho + ho) * Wo + wo) * C + c, m);
   }
@@ -276,7 +408,12 @@ extern "C" int st_bn_act(const st_bn_act_desc* d, void* stream) {
   const int grid = grid_for(nchunk, 256);
   const size_t lds = (size_t)(d->res_bn ? 4 : 2) * d->C * sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == ST_BF16) hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, *d);
+  ST_CHECK(d->stats_replicas >= 0 && d->res_stats_replicas >= 0, "st_bn_act: bad replica count");
+  const bool reg = d->stats_replicas <= 1 && d->res_stats_replicas <= 1 && (256 * n) % d->C == 0;
+  if (reg) {
+    if (d->dtype == ST_BF16) hipLaunchKernelGGL(bn_act_reg_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, *d);
+    else hipLaunchKernelGGL(bn_act_reg_kernel<float>, dim3(grid), dim3(256), 0, st, *d);
+  } else if (d->dtype == ST_BF16) hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, *d);
   else hipLaunchKernelGGL(bn_act_kernel<float>, dim3(grid), dim3(256), lds, st, *d);
   ST_LAUNCH_CHECK();
   return 0;
@@ -302,6 +439,29 @@ extern "C" int st_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C,
   return 0;
 }
 
+extern "C" int st_nchw_to_s2d16(const float* x, void* y, int dtype, int B, int H, int W, void* stream) {
+  ST_CHECK(x && y, "st_nchw_to_s2d16: null pointer");
+  ST_DT_CHECK(dtype, "st_nchw_to_s2d16");
+  ST_CHECK(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "st_nchw_to_s2d16: H=%d, W=%d must be even", H, W);
+  const int grid = grid_for((long)B * (H / 2 + 3) * (W / 2 + 3), 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(nchw_to_s2d_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t*)y, B, H, W);
+  else hipLaunchKernelGGL(nchw_to_s2d_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)y, B, H, W);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_stem_weight_s2d(const void* w, void* out, int dtype, int Cpad, void* stream) {
+  ST_CHECK(w && out, "st_stem_weight_s2d: null pointer");
+  ST_DT_CHECK(dtype, "st_stem_weight_s2d");
+  ST_CHECK(Cpad >= 3, "st_stem_weight_s2d: bad Cpad=%d", Cpad);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(stem_weight_s2d_kernel<bf16_t>, dim3(64), dim3(256), 0, st, (const bf16_t*)w, (bf16_t*)out, Cpad);
+  else hipLaunchKernelGGL(stem_weight_s2d_kernel<float>, dim3(64), dim3(256), 0, st, (const float*)w, (float*)out, Cpad);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int st_nhwc_to_ncp_f32(const void* x, float* y, int dtype, int B, int HW, int C, void* stream) {
   ST_CHECK(x && y, "st_nhwc_to_ncp_f32: null pointer");
   ST_DT_CHECK(dtype, "st_nhwc_to_ncp_f32");
@@ -323,8 +483,26 @@ extern "C" int st_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, 
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int grid = grid_for((long)B * Ho * Wo * (C / n), 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ST_BF16) hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
-  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
+  BnArgs bn; memset(&bn, 0, sizeof(bn));
+  if (dtype == ST_BF16) hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo, bn);
+  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, Ho, Wo, bn);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int st_maxpool3x3s2_bn(const void* x, void* y, int dtype, int B, int H, int W, int C,
+                                  const float* stats, const float* gamma, const float* beta,
+                                  const float* running_mean, const float* running_var, float count, float eps, void* stream) {
+  ST_CHECK(x && y && gamma && beta && (stats || (running_mean && running_var)), "st_maxpool3x3s2_bn: null pointer");
+  ST_DT_CHECK(dtype, "st_maxpool3x3s2_bn");
+  const int n = dtype == ST_BF16 ? 8 : 4;
+  ST_CHECK(C % n == 0 && (256 * n) % C == 0, "st_maxpool3x3s2_bn: C=%d must divide %d", C, 256 * n);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int grid = grid_for((long)B * Ho * Wo * (C / n), 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  BnArgs bn{1, stats, gamma, beta, running_mean, running_var, 1.0f / count, eps};
+  if (dtype == ST_BF16) hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo, bn);
+  else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, Ho, Wo, bn);
   ST_LAUNCH_CHECK();
   return 0;
 }

@@ -13,32 +13,51 @@
 
 namespace {
 
+// BatchNorm1d over [B][E] fp32: a block owns 32 columns, its 8 row groups stride over the batch and meet in LDS
+// (128-byte coalesced row segments, E/32 blocks instead of one serial thread per column).
+constexpr int kBnTX = 32, kBnTY = 8;
+__device__ __forceinline__ float bn1d_colsum(float v, float (*red)[kBnTX]) {
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  __syncthreads();                      // previous use of red is over
+  red[ty][tx] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kBnTY; ++k) s += red[k][tx];
+  return s;
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ rm, float* __restrict__ rv, float* __restrict__ save_mean,
                                                        float* __restrict__ save_rstd, TO* __restrict__ y, float* __restrict__ y_f32,
                                                        int B, int E, int train, float mom, float eps) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  float mean, rstd;
+  __shared__ float red[kBnTY][kBnTX];
+  const int e = blockIdx.x * kBnTX + threadIdx.x, ty = threadIdx.y;
+  const bool ok = e < E;
+  float mean = 0.f, rstd = 0.f;
   if (train) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += z[(long)b * E + e];
-    mean = s / B;
+    if (ok) for (int b = ty; b < B; b += kBnTY) s += z[(long)b * E + e];
+    mean = bn1d_colsum(s, red) / B;
     float v = 0.f;
-    for (int b = 0; b < B; ++b) { const float d = z[(long)b * E + e] - mean; v += d * d; }
+    if (ok) for (int b = ty; b < B; b += kBnTY) { const float d = z[(long)b * E + e] - mean; v += d * d; }
+    v = bn1d_colsum(v, red);
     const float var = v / B;
     rstd = rsqrtf(var + eps);
-    const float unb = B > 1 ? v / (B - 1) : var;
-    rm[e] = (1.f - mom) * rm[e] + mom * mean;
-    rv[e] = (1.f - mom) * rv[e] + mom * unb;
-  } else {
+    if (ok && ty == 0) {
+      const float unb = B > 1 ? v / (B - 1) : var;
+      rm[e] = (1.f - mom) * rm[e] + mom * mean;
+      rv[e] = (1.f - mom) * rv[e] + mom * unb;
+    }
+  } else if (ok) {
     mean = rm[e];
     rstd = rsqrtf(rv[e] + eps);
   }
-  if (save_mean) { save_mean[e] = mean; save_rstd[e] = rstd; }
+  if (!ok) return;
+  if (save_mean && ty == 0) { save_mean[e] = mean; save_rstd[e] = rstd; }
   const float g = gamma[e] * rstd, sh = beta[e] - mean * g;
-  for (int b = 0; b < B; ++b) {
+  for (int b = ty; b < B; b += kBnTY) {
     const float o = z[(long)b * E + e] * g + sh;
     if (y) y[(long)b * E + e] = from_f32<TO>(o);
     if (y_f32) y_f32[(long)b * E + e] = o;
@@ -50,18 +69,21 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, TO* __restrict__ dz,
                                                        int B, int E, int ldz, int train) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const float mean = save_mean[e], rstd = save_rstd[e], g = gamma[e];
+  __shared__ float red[kBnTY][kBnTX];
+  const int e = blockIdx.x * kBnTX + threadIdx.x, ty = threadIdx.y;
+  const bool ok = e < E;
+  const float mean = ok ? save_mean[e] : 0.f, rstd = ok ? save_rstd[e] : 0.f, g = ok ? gamma[e] : 0.f;
   float sdy = 0.f, sdyx = 0.f;
-  for (int b = 0; b < B; ++b) {
+  if (ok) for (int b = ty; b < B; b += kBnTY) {
     const float d = dy[(long)b * E + e], xh = (z[(long)b * E + e] - mean) * rstd;
     sdy += d; sdyx += d * xh;
   }
-  dgamma[e] += sdyx;
-  dbeta[e] += sdy;
+  sdy = bn1d_colsum(sdy, red);
+  sdyx = bn1d_colsum(sdyx, red);
+  if (!ok) return;
+  if (ty == 0) { dgamma[e] += sdyx; dbeta[e] += sdy; }
   const float m1 = sdy / B, m2 = sdyx / B;
-  for (int b = 0; b < B; ++b) {
+  for (int b = ty; b < B; b += kBnTY) {
     const float d = dy[(long)b * E + e], xh = (z[(long)b * E + e] - mean) * rstd;
     const float o = train ? g * rstd * (d - m1 - xh * m2) : g * rstd * d;
     dz[(long)b * ldz + e] = from_f32<TO>(o);
@@ -147,7 +169,7 @@ extern "C" int st_linear_bn1d_forward(const void* x, const void* w, const float*
   ST_CHECK(!train || B > 1, "Expected more than 1 value per channel when training (BatchNorm1d, B=%d)", B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (gemm_nt_(x, F, w, F, z_out, E, B, E, F, dtype, ST_F32, bias, 0, stream)) return 1;
-  const dim3 grid((E + 255) / 256), block(256);
+  const dim3 grid((E + kBnTX - 1) / kBnTX), block(kBnTX, kBnTY);
   if (dtype == ST_BF16)
     hipLaunchKernelGGL(bn1d_fwd_kernel<bf16_t>, grid, block, 0, st, z_out, gamma, beta, running_mean, running_var, save_mean, save_rstd,
                        (bf16_t*)y_dtype, y_f32, B, E, train, momentum, eps);
@@ -171,7 +193,7 @@ extern "C" int st_linear_bn1d_backward(const float* dy, const float* z, const vo
   char* dz = ws; ws += al((size_t)B * Ep * es);
   char* dzT = ws; ws += al((size_t)E * Bp * es);
   char* xT = ws;
-  const dim3 grid((E + 255) / 256), block(256);
+  const dim3 grid((E + kBnTX - 1) / kBnTX), block(kBnTX, kBnTY);
   if (dtype == ST_BF16)
     hipLaunchKernelGGL(bn1d_bwd_kernel<bf16_t>, grid, block, 0, st, dy, z, gamma, save_mean, save_rstd, dgamma, dbeta, (bf16_t*)dz, B, E, Ep, train);
   else

@@ -45,7 +45,7 @@ struct IgemmArgs {
   int M, N, K;
   int Hin, Win, Cin, Ho, Wo, KH, KW, stride, pad;
   int ldx, ldw, ldy;
-  int relu, accumulate, out_f32, korder;
+  int relu, accumulate, out_f32, korder, srep;
   int nbm, nbn;
   double flops;   // algorithmic 2*M*N*K (host side only, profiler)
 };
@@ -122,13 +122,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       }
     }
     epi_barrier<RAWB>();
+    float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);   // replica of this pixel tile
     if (storer) for (int t = stid; t < 2 * BN; t += NT) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) v += red[t * WM + w];
       const int nl = t < BN ? t : t - BN;
       const int n = bn * BN + nl;
-      if (n < a.N) atomicAdd(a.stats + (t < BN ? n : a.N + n), v);
+      if (n < a.N) atomicAdd(sdst + (t < BN ? n : a.N + n), v);
     }
   }
 
@@ -452,8 +453,11 @@ int dispatch_kc(IgemmArgs& a, hipStream_t st) {
 
 template <typename T>
 int dispatch(IgemmArgs& a, hipStream_t st) {
+  // 64-byte tile rows halve the LDS footprint (3-4 blocks per CU instead of 2): the short-K pointwise layers
+  // (K <= 256: 4 K steps or fewer, prologue/epilogue-bound) gain 8-15 % from the extra overlap, long-K layers lose.
   const int kc = tuning_kc();
-  if (kc == 4 && !a.korder) return dispatch_kc<T, 4>(a, st);
+  const bool short_k = a.KH * a.KW == 1 && a.K <= 256 && a.K % 64 == 0 && a.M >= 4096;
+  if ((kc == 4 || (kc == 0 && short_k)) && !a.korder) return dispatch_kc<T, 4>(a, st);
   return dispatch_kc<T, 8>(a, st);
 }
 
@@ -465,7 +469,12 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   const int epc = d->dtype == ST_BF16 ? 8 : 4;
   ST_CHECK(d->Cin > 0 && d->Cin % epc == 0, "st_conv: Cin=%d must be a multiple of %d", d->Cin, epc);
   ST_CHECK(d->ldx % epc == 0 && d->ldw % epc == 0, "st_conv: ldx=%d/ldw=%d must be multiples of %d", d->ldx, d->ldw, epc);
-  ST_CHECK(d->ldx >= d->Cin && d->ldw >= d->KH * d->KW * d->Cin, "st_conv: leading dimensions too small");
+  const bool sliding = d->ldx < d->Cin;   // Cin/ldx neighbouring pixels of a row form one tap (space-to-depth stem)
+  ST_CHECK(!sliding || (d->KW == 1 && d->pad == 0 && d->Cin % d->ldx == 0 && !d->k_order &&
+                        (d->Wo - 1) * d->stride + d->Cin / d->ldx <= d->Win && (d->Ho - 1) * d->stride + d->KH <= d->Hin),
+           "st_conv: sliding-window input needs KW=1, pad=0, Cin %% ldx == 0 and rows padded by the caller");
+  ST_CHECK(d->ldw >= d->KH * d->KW * d->Cin, "st_conv: leading dimensions too small");
+  ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024, "st_conv: bad stats_replicas");
   ST_CHECK(d->ldy % 4 == 0 && d->ldy >= d->N, "st_conv: ldy=%d must be a multiple of 4 and >= N=%d", d->ldy, d->N);
   ST_CHECK(d->B > 0 && d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0, "st_conv: bad geometry");
   ST_CHECK(d->Hin < 32768 && d->Win < 32768, "st_conv: spatial size too large");
@@ -480,7 +489,7 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy;
   a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == ST_F32;
-  a.korder = d->k_order;
+  a.korder = d->k_order; a.srep = d->stats_replicas;
   a.flops = 2.0 * a.M * a.N * d->KH * d->KW * (d->Cin_logical > 0 ? d->Cin_logical : d->Cin);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == ST_BF16 ? dispatch<bf16_t>(a, st) : dispatch<float>(a, st);

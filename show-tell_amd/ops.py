@@ -36,8 +36,9 @@ def _dev(*ts):
 
 
 def conv_nhwc(x, w, KH, KW, stride, pad, out_dtype=None, bias=None, scale=None, shift=None,
-              residual=None, stats=None, relu=False, out=None, accumulate=False, k_order=0):
-    """x: (B,Hin,Win,Cin) NHWC; w: (N, KH*KW*Cin) K-contiguous.  Returns (B,Ho,Wo,N)."""
+              residual=None, stats=None, relu=False, out=None, accumulate=False, k_order=0, stats_replicas=0):
+    """x: (B,Hin,Win,Cin) NHWC; w: (N, KH*KW*Cin) K-contiguous.  Returns (B,Ho,Wo,N).
+    stats_replicas = R > 1: stats is (R, 2N), pixel tile t adds into replica t % R."""
     _dev(x, w, bias, scale, shift, residual, stats, out)
     B, Hin, Win, Cin = x.shape
     N = w.shape[0]
@@ -50,9 +51,27 @@ def conv_nhwc(x, w, KH, KW, stride, pad, out_dtype=None, bias=None, scale=None, 
     assert out.shape == (B, Ho, Wo, N) and out.dtype == out_dtype
     d = ConvDesc(_p(x), _p(w), _p(out), _p(bias), _p(scale), _p(shift), _p(residual), _p(stats),
                  dt_code(x), _DT[out_dtype], B, Hin, Win, Cin, Ho, Wo, N, KH, KW, stride, pad,
-                 Cin, w.shape[1], N, int(relu), int(accumulate), 0, int(k_order))
+                 Cin, w.shape[1], N, int(relu), int(accumulate), 0, int(k_order), int(stats_replicas))
     check(lib().st_conv(C.byref(d), _stream()), "st_conv")
     return out
+
+
+def stem_conv_s2d(images, w_packed, cpad, dtype, stats=None, scale=None, shift=None, relu=False):
+    """torchvision stem (7x7 s2 p3 over RGB, cnn.py:46) through the space-to-depth route: images (B,3,H,W) fp32 with
+    even H, W; w_packed the usual (64, 7*7*cpad) k_order-0 weights.  Returns (B,H/2,W/2,64)."""
+    _dev(images, w_packed, stats, scale, shift)
+    B, Cc, H, W = images.shape
+    assert Cc == 3 and images.dtype == torch.float32
+    xs = torch.empty(B, H // 2 + 3, W // 2 + 3, 16, device=images.device, dtype=dtype)
+    check(lib().st_nchw_to_s2d16(_p(images), _p(xs), _DT[dtype], B, H, W, _stream()), "st_nchw_to_s2d16")
+    ws = torch.empty(64, 256, device=images.device, dtype=dtype)
+    check(lib().st_stem_weight_s2d(_p(w_packed), _p(ws), _DT[dtype], cpad, _stream()), "st_stem_weight_s2d")
+    out = torch.empty(B, H // 2, W // 2, 64, device=images.device, dtype=dtype)
+    d = ConvDesc(_p(xs), _p(ws), _p(out), None, _p(scale), _p(shift), None, _p(stats),
+                 _DT[dtype], _DT[dtype], B, H // 2 + 3, W // 2 + 3, 64, H // 2, W // 2, 64, 4, 1, 1, 0,
+                 16, 256, 64, int(relu), 0, 36, 0, 0)
+    check(lib().st_conv(C.byref(d), _stream()), "st_conv(s2d stem)")
+    return out, xs, ws
 
 
 def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=None, relu=False,
@@ -76,7 +95,7 @@ def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=N
 
 
 def bn_act(x, gamma, beta, stats=None, running=None, count=1.0, eps=1e-5, relu=True, res=None,
-           res_bn=None, out=None):
+           res_bn=None, out=None, stats_replicas=0):
     """x: (..., C) channels-last.  res_bn = dict(gamma, beta, stats | running=(mean,var)) or None."""
     _dev(x, gamma, beta, stats, res, out)
     Cc = x.shape[-1]
@@ -88,7 +107,8 @@ def bn_act(x, gamma, beta, stats=None, running=None, count=1.0, eps=1e-5, relu=T
     rrm, rrv = rb.get("running", (None, None))
     d = BnActDesc(_p(x), _p(out), _p(res), _p(stats), _p(gamma), _p(beta), _p(rm), _p(rv),
                   _p(rb.get("stats")), _p(rb.get("gamma")), _p(rb.get("beta")), _p(rrm), _p(rrv),
-                  int(res_bn is not None), dt_code(x), rows, Cc, float(count), float(eps), int(relu))
+                  int(res_bn is not None), dt_code(x), rows, Cc, float(count), float(eps), int(relu),
+                  int(stats_replicas), int(rb.get("stats_replicas", 0)))
     check(lib().st_bn_act(C.byref(d), _stream()), "st_bn_act")
     return out
 
@@ -122,6 +142,18 @@ def maxpool3x3s2(x):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
     check(lib().st_maxpool3x3s2(_p(x), _p(y), dt_code(x), B, H, W, Cc, _stream()), "st_maxpool3x3s2")
+    return y
+
+
+def maxpool3x3s2_bn(x, gamma, beta, stats=None, running=None, count=1.0, eps=1e-5):
+    """maxpool3x3s2(relu(batchnorm(x))) in one pass (the ResNet stem tail)."""
+    _dev(x, gamma, beta, stats)
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
+    rm, rv = running if running is not None else (None, None)
+    check(lib().st_maxpool3x3s2_bn(_p(x), _p(y), dt_code(x), B, H, W, Cc, _p(stats), _p(gamma), _p(beta), _p(rm), _p(rv),
+                                   float(count), float(eps), _stream()), "st_maxpool3x3s2_bn")
     return y
 
 

@@ -144,6 +144,102 @@ def test_bn_act_residual_variants(dtype, train):
     _close(y.permute(0, 3, 1, 2), F.relu(bn(x, gam, bet) + bn(r, gam2, bet2)), dtype, "bn+bn(res)+relu")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cc,R", [(64, 4), (96, 1), (256, 3)])
+def test_conv_stats_replicas_feed_bn_act(dtype, Cc, R):
+    """Replicated batch statistics (st_conv_desc.stats_replicas): the replicas sum to the single-buffer statistics and
+    bn_act normalises from them exactly as from one buffer (LDS-table path; C=96 also covers it with R=1)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(Cc + R)
+    B, H, Cin = 6, 20, 32                                   # M = 2400 -> 19 pixel tiles
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cc, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    res = torch.randn(B, H, H, Cc, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, res = x.bfloat16().float(), w.bfloat16().float(), res.bfloat16().float()
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", dtype)
+    wd = ops.pack_conv_weight(w.cuda(), dtype)
+    one = torch.zeros(2 * Cc, device="cuda")
+    rep = torch.zeros(R, 2 * Cc, device="cuda")
+    y1 = ops.conv_nhwc(xd, wd, 1, 1, 1, 0, stats=one)
+    y2 = ops.conv_nhwc(xd, wd, 1, 1, 1, 0, stats=rep, stats_replicas=R)
+    assert torch.equal(y1, y2)
+    if R > 1:
+        assert (rep.abs().sum(1) > 0).all(), "every replica receives tiles"
+    np.testing.assert_allclose(rep.sum(0).cpu().numpy(), one.cpu().numpy(), rtol=2e-5, atol=2e-3)
+    gam, bet = (torch.rand(Cc, generator=g) + 0.5).cuda(), torch.randn(Cc, generator=g).cuda()
+    n = B * H * H
+    rd = res.to("cuda", dtype)
+    a = ops.bn_act(y1, gam, bet, stats=one, count=n, relu=True, res=rd)
+    b = ops.bn_act(y1, gam, bet, stats=rep, count=n, relu=True, res=rd, stats_replicas=R)
+    _close(b, a.float().cpu(), dtype, "bn_act from replicas")
+    # and against torch
+    yr = F.conv2d(x, w)
+    ref = F.relu(F.batch_norm(yr, None, None, gam.cpu(), bet.cpu(), True, 0.1, 1e-5).permute(0, 2, 3, 1) + res)
+    _close(b, ref, dtype, "conv+bn(train)+res+relu")
+    # residual branch with its own replicated statistics
+    c = ops.bn_act(y1, gam, bet, stats=one, count=n, relu=False, res=y1, res_bn=dict(gamma=gam, beta=bet, stats=one))
+    d = ops.bn_act(y1, gam, bet, stats=rep, count=n, relu=False, res=y1, stats_replicas=R,
+                   res_bn=dict(gamma=gam, beta=bet, stats=rep, stats_replicas=R))
+    _close(d, c.float().cpu(), dtype, "bn_act + bn(res) from replicas")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 32, 48), (1, 224, 224)])
+def test_stem_space_to_depth_matches_conv7x7(dtype, B, H, W):
+    """The blocked-image stem (st_nchw_to_s2d16 + st_stem_weight_s2d + sliding-window st_conv) is the same sum as
+    torchvision's conv1 (7x7, stride 2, pad 3; cnn.py:46)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / np.sqrt(147)
+    cpad = 8 if dtype == torch.bfloat16 else 4
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x, w, None, 2, 3).permute(0, 2, 3, 1).contiguous()
+    wpad = torch.zeros(64, cpad, 7, 7)
+    wpad[:, :3] = w
+    wd = ops.pack_conv_weight(wpad.cuda(), dtype)
+    stats = torch.zeros(128, device="cuda")
+    y, xs, ws = ops.stem_conv_s2d(x.cuda(), wd, cpad, dtype, stats=stats)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    _close(y, ref, dtype, "s2d stem")
+    r2 = ref.reshape(-1, 64)
+    _close(stats[:64], r2.sum(0), dtype, "sum")
+    _close(stats[64:], (r2 * r2).sum(0), dtype, "sumsq")
+    # layout facts: zero border / pad channels, and the blocked pixel content
+    xs = xs.float().cpu()
+    assert xs[:, :2].abs().max() == 0 and xs[:, -1].abs().max() == 0 and xs[:, :, :2].abs().max() == 0 and xs[:, :, -1].abs().max() == 0
+    assert xs[..., 12:].abs().max() == 0
+    blk = xs[:, 2:-1, 2:-1, :12].reshape(B, H // 2, W // 2, 2, 2, 3)          # (dy, dx, c)
+    want = x.reshape(B, 3, H // 2, 2, W // 2, 2).permute(0, 2, 4, 3, 5, 1)
+    assert torch.equal(blk, want.to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_bn_equals_two_pass(dtype):
+    """st_maxpool3x3s2_bn (stem tail of torchvision's resnet: bn1, relu, maxpool) == bn_act then maxpool, bit for bit,
+    and matches torch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cc = 3, 18, 22, 64
+    x = torch.randn(B, Cc, H, W, generator=g) * 2 - 0.3
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    gam, bet = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)     # negative gammas included
+    xl = x.permute(0, 2, 3, 1).contiguous()
+    x2 = xl.reshape(-1, Cc)
+    stats = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).cuda()
+    xd = xl.to("cuda", dtype)
+    n = B * H * W
+    two = ops.maxpool3x3s2(ops.bn_act(xd, gam.cuda(), bet.cuda(), stats=stats, count=n, relu=True))
+    one = ops.maxpool3x3s2_bn(xd, gam.cuda(), bet.cuda(), stats=stats, count=n)
+    assert torch.equal(one, two)
+    ref = F.max_pool2d(F.relu(F.batch_norm(x, None, None, gam, bet, True, 0.1, 1e-5)), 3, 2, 1).permute(0, 2, 3, 1)
+    _close(one, ref, dtype, "bn+relu+maxpool")
+
+
 def test_bn_update_running_matches_torch():
     ops = _ops()
     g = torch.Generator().manual_seed(9)
