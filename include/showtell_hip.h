@@ -129,6 +129,9 @@ int st_global_avgpool(const void* x, void* y, int dtype, int out_dtype, int B, i
 int st_cast(const void* x, void* y, int from_dtype, int to_dtype, long n, void* stream);
 /* y[c][r] = x[r][c]; y has leading dimension ldy >= rows, pad columns zero-filled */
 int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx, int ldy, void* stream);
+/* the same, and colsum[c] += sum_r x[r][c] (fp32 atomics) from the tile already in LDS: the bias gradient that goes with
+ * every K-major copy of a gradient matrix in the decoder backward (autograd of nn.Linear / nn.GRU, main.py:151) */
+int st_transpose_colsum(const void* x, void* y, float* colsum, int dtype, int rows, int cols, int ldx, int ldy, void* stream);
 /* conv weight repack: [Cout][Cin][KH][KW] fp32 (torch layout) -> [Cout][KH][KW][Cpad] dtype (k_order 0)
  * or [Cout][Cpad/CH][KH][KW][CH] with CH = 64 (bf16) / 32 (f32) channels (k_order 1, see st_conv_desc) */
 int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, int k_order, void* stream);

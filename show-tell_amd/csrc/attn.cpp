@@ -237,8 +237,7 @@ extern "C" int st_attn_backward(const st_attn_params* p, const st_attn_grads* g,
   float* datt2 = reinterpret_cast<float*>(ws + q.datt2);
 
   // vocabulary projection
-  if (colsum_launch(dlogits, g->rnn.b_lin, n, r.V, ldd, dt, st)) return 1;
-  if (st_transpose(dlogits, ws + q.tA, dt, n, r.V, ldd, Np, stream)) return 1;
+  if (st_transpose_colsum(dlogits, ws + q.tA, g->rnn.b_lin, dt, n, r.V, ldd, Np, stream)) return 1;
   if (st_transpose(ytop, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
   if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->rnn.w_lin, H, r.V, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
   if (st_transpose(r.w_lin, ws + q.wTmisc, dt, r.V, H, H, q.Vp, stream)) return 1;
@@ -307,29 +306,25 @@ extern "C" int st_attn_backward(const st_attn_params* p, const st_attn_grads* g,
     const char* xl = l == 0 ? ws + q.xp : ws + q.y + (size_t)(l - 1) * n * H * es;
     char* dgx = ws + q.dgx + (size_t)l * n * GH * es;
     char* dgh = r.cell == ST_CELL_GRU ? ws + q.dgh + (size_t)l * n * GH * es : dgx;
-    if (colsum_launch(dgx, g->rnn.b_ih[l], n, GH, GH, dt, st)) return 1;
-    if (colsum_launch(dgh, g->rnn.b_hh[l], n, GH, GH, dt, st)) return 1;
-    if (st_transpose(dgx, ws + q.tA, dt, n, GH, GH, Np, stream)) return 1;
+    if (r.cell != ST_CELL_GRU && colsum_launch(dgh, g->rnn.b_hh[l], n, GH, GH, dt, st)) return 1;   // LSTM: dgh == dgx
+    if (st_transpose_colsum(dgx, ws + q.tA, g->rnn.b_ih[l], dt, n, GH, GH, Np, stream)) return 1;
     if (st_transpose(xl, ws + q.tB, dt, n, in, in, Np, stream)) return 1;
     if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->rnn.w_ih[l], in, GH, in, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
     if (gather_hprev_launch(ws + q.y + (size_t)l * n * H * es, s->rows_t, s->prev_row, ws + q.hprev, n, H, dt, st, ws + q.h0, s->rows_b)) return 1;
-    if (r.cell == ST_CELL_GRU && st_transpose(dgh, ws + q.tA, dt, n, GH, GH, Np, stream)) return 1;
+    if (r.cell == ST_CELL_GRU && st_transpose_colsum(dgh, ws + q.tA, g->rnn.b_hh[l], dt, n, GH, GH, Np, stream)) return 1;
     if (st_transpose(ws + q.hprev, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
     if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->rnn.w_hh[l], H, GH, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
   }
   // decoder_att: d att2 rows x previous top state (hprev of the last layer is still in q.hprev / tB)
-  if (colsum_launch(ws + q.datt2p, g->b_dec, n, A, A, dt, st)) return 1;
-  if (st_transpose(ws + q.datt2p, ws + q.tA, dt, n, A, A, Np, stream)) return 1;
+  if (st_transpose_colsum(ws + q.datt2p, ws + q.tA, g->b_dec, dt, n, A, A, Np, stream)) return 1;
   if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_dec, H, A, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
   // embed: d ez rows x z rows
-  if (colsum_launch(ws + q.dez, g->b_embed, n, E, E, dt, st)) return 1;
-  if (st_transpose(ws + q.dez, ws + q.tA, dt, n, E, E, Np, stream)) return 1;
+  if (st_transpose_colsum(ws + q.dez, ws + q.tA, g->b_embed, dt, n, E, E, Np, stream)) return 1;
   if (st_transpose(ws + q.z, ws + q.tB, dt, n, F, F, Np, stream)) return 1;
   if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_embed, F, E, F, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
   // encoder_att: time-summed d att1 (B*P rows) x feat
   if (st_cast(datt1, ws + q.cast, ST_F32, dt, (long)BP * A, stream)) return 1;
-  if (colsum_launch(ws + q.cast, g->b_enc, BP, A, A, dt, st)) return 1;
-  if (st_transpose(ws + q.cast, ws + q.tA, dt, BP, A, A, Np, stream)) return 1;
+  if (st_transpose_colsum(ws + q.cast, ws + q.tA, g->b_enc, dt, BP, A, A, Np, stream)) return 1;
   if (st_transpose(ws + q.feat, ws + q.tB, dt, BP, F, F, Np, stream)) return 1;
   if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_enc, F, A, F, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
   // init_h (init_c): every layer started from the same h0, so its gradient is the sum over layers
@@ -340,8 +335,7 @@ extern "C" int st_attn_backward(const st_attn_params* p, const st_attn_grads* g,
     if (st_cast(acc, ws + q.cast, ST_F32, dt, (long)B * H, stream)) return 1;
     float* gw = pass == 0 ? g->w_init_h : g->w_init_c;
     float* gb = pass == 0 ? g->b_init_h : g->b_init_c;
-    if (colsum_launch(ws + q.cast, gb, B, H, H, dt, st)) return 1;
-    if (st_transpose(ws + q.cast, ws + q.tA, dt, B, H, H, Bp, stream)) return 1;
+    if (st_transpose_colsum(ws + q.cast, ws + q.tA, gb, dt, B, H, H, Bp, stream)) return 1;
     if (st_transpose(ws + q.mean, ws + q.tB, dt, B, F, F, Bp, stream)) return 1;
     if (gemm_nt(ws + q.tA, Bp, ws + q.tB, Bp, gw, F, H, F, Bp, dt, ST_F32, nullptr, 1, stream)) return 1;
   }

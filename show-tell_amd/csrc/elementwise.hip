@@ -347,20 +347,51 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const TI* __restrict__ x, T
   }
 }
 
+// y[c][r] = x[r][c] over 64x64 tiles, 16-byte global accesses on both sides (rows >= `rows` read as zero, so the pad
+// columns of y up to ldy are zero-filled); optionally colsum[c] += sum_r x[r][c] from the same tile -- the bias
+// gradient that always accompanies the K-major copy of a gradient matrix in the decoder backward.
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ colsum,
                                                          int rows, int cols, int ldx, int ldy) {
-  __shared__ T tile[64][65];
+  constexpr int N = Vec<T>::N, CPR = 64 / N;       // elements per 16 bytes, chunks per 64-element tile row
+  constexpr int LD = 64 + (sizeof(T) == 2 ? 2 : 1);
+  __shared__ T tile[64][LD];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int i = ty; i < 64; i += 4) {
-    const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < rows && c < cols) ? x[(long)r * ldx + c] : from_f32<T>(0.f);
+  const bool vec_in = (ldx % N == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
+    const int rl = i / CPR, cl = (i % CPR) * N;
+    const int r = r0 + rl, c = c0 + cl;
+    float v[N];
+    if (r < rows && c + N <= cols && vec_in) {
+      Vec<T>::load(x + (long)r * ldx + c, v);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = (r < rows && c + k < cols) ? to_f32<T>(x[(long)r * ldx + c + k]) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) tile[rl][cl + k] = from_f32<T>(v[k]);
   }
   __syncthreads();
-  for (int i = ty; i < 64; i += 4) {
-    const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < ldy) y[(long)c * ldy + r] = tile[tx][i];
+  if (colsum && threadIdx.x < 64 && c0 + threadIdx.x < cols) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) sum += to_f32<T>(tile[r][threadIdx.x]);
+    atomicAdd(colsum + c0 + threadIdx.x, sum);
+  }
+  const bool vec_out = (ldy % N == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
+    const int cl = i / CPR, rl = (i % CPR) * N;
+    const int c = c0 + cl, r = r0 + rl;
+    if (c >= cols || r >= ldy) continue;
+    float v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = to_f32<T>(tile[rl + k][cl]);
+    if (r + N <= ldy && vec_out) {
+      Vec<T>::store(y + (long)c * ldy + r, v);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) if (r + k < ldy) y[(long)c * ldy + r + k] = from_f32<T>(v[k]);
+    }
   }
 }
 
@@ -554,16 +585,20 @@ extern "C" int st_cast2d(const void* x, void* y, int from_dtype, int to_dtype, i
   return 0;
 }
 
-extern "C" int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx, int ldy, void* stream) {
+extern "C" int st_transpose_colsum(const void* x, void* y, float* colsum, int dtype, int rows, int cols, int ldx, int ldy, void* stream) {
   ST_CHECK(x && y, "st_transpose: null pointer");
   ST_DT_CHECK(dtype, "st_transpose");
   ST_CHECK(ldx >= cols && ldy >= rows, "st_transpose: leading dimensions too small (rows=%d cols=%d ldx=%d ldy=%d)", rows, cols, ldx, ldy);
   const dim3 grid((cols + 63) / 64, (ldy + 63) / 64);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ST_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, cols, ldx, ldy);
-  else hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, rows, cols, ldx, ldy);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, colsum, rows, cols, ldx, ldy);
+  else hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, colsum, rows, cols, ldx, ldy);
   ST_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx, int ldy, void* stream) {
+  return st_transpose_colsum(x, y, nullptr, dtype, rows, cols, ldx, ldy, stream);
 }
 
 extern "C" int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, int k_order, void* stream) {

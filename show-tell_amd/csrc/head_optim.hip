@@ -200,8 +200,7 @@ extern "C" int st_linear_bn1d_backward(const float* dy, const float* z, const vo
     hipLaunchKernelGGL(bn1d_bwd_kernel<float>, grid, block, 0, st, dy, z, gamma, save_mean, save_rstd, dgamma, dbeta, (float*)dz, B, E, Ep, train);
   ST_LAUNCH_CHECK();
   // db += colsum(dz) ; dW += dz^T x
-  if (colsum_launch(dz, dbias, B, E, Ep, dtype, st)) return 1;
-  if (st_transpose(dz, dzT, dtype, B, E, Ep, Bp, stream)) return 1;
+  if (st_transpose_colsum(dz, dzT, dbias, dtype, B, E, Ep, Bp, stream)) return 1;
   if (st_transpose(x, xT, dtype, B, F, F, Bp, stream)) return 1;
   return gemm_nt_(dzT, Bp, xT, Bp, dw, F, E, F, Bp, dtype, ST_F32, nullptr, 1, stream);
 }

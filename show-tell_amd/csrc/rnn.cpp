@@ -176,8 +176,7 @@ extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, co
     ST_CHECK(p->w_lin && g->w_lin && g->b_lin, "st_rnn_backward: vocabulary projection gradients requested without buffers");
     ST_CHECK(ldd >= q.Vp && ldd % 8 == 0, "st_rnn_backward: dlogits leading dimension %d must be a multiple of 8 and >= %d", ldd, q.Vp);
     // db = colsum(dlogits);  dW_lin += dlogits^T y_top;  dy_top = dlogits W_lin
-    if (colsum_launch(dlogits, g->b_lin, n, p->V, ldd, dt, st)) return 1;
-    if (st_transpose(dlogits, ws + q.tA, dt, n, p->V, ldd, Np, stream)) return 1;
+    if (st_transpose_colsum(dlogits, ws + q.tA, g->b_lin, dt, n, p->V, ldd, Np, stream)) return 1;
     if (st_transpose(ytop, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
     if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_lin, H, p->V, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
     if (st_transpose(p->w_lin, ws + q.wT, dt, p->V, H, H, q.Vp, stream)) return 1;
@@ -225,13 +224,13 @@ extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, co
       }
     }
     // parameter gradients of this layer
-    if (colsum_launch(dgx, g->b_ih[l], n, GH, GH, dt, st)) return 1;
-    if (colsum_launch(dgh, g->b_hh[l], n, GH, GH, dt, st)) return 1;
-    if (st_transpose(dgx, ws + q.tA, dt, n, GH, GH, Np, stream)) return 1;
+    // bias gradients ride on the K-major copies (column sums of the tile already in LDS)
+    if (p->cell != ST_CELL_GRU && colsum_launch(dgh, g->b_hh[l], n, GH, GH, dt, st)) return 1;   // LSTM: dgh == dgx, transposed once
+    if (st_transpose_colsum(dgx, ws + q.tA, g->b_ih[l], dt, n, GH, GH, Np, stream)) return 1;
     if (st_transpose(xl, ws + q.tB, dt, n, in, in, Np, stream)) return 1;
     if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_ih[l], in, GH, in, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
     if (gather_hprev_launch(yl, s->rows_t, s->prev_row, ws + q.hprev, n, H, dt, st)) return 1;
-    if (p->cell == ST_CELL_GRU && st_transpose(dgh, ws + q.tA, dt, n, GH, GH, Np, stream)) return 1;
+    if (p->cell == ST_CELL_GRU && st_transpose_colsum(dgh, ws + q.tA, g->b_hh[l], dt, n, GH, GH, Np, stream)) return 1;
     if (st_transpose(ws + q.hprev, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
     if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_hh[l], H, GH, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
     // dx_l = dgx W_ih  -> gradient w.r.t. the layer below (fp32)

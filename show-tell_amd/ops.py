@@ -174,14 +174,15 @@ def cast(x, dtype, out=None):
     return out
 
 
-def transpose(x, ldy=None, out=None):
-    """x: (rows, cols) -> (cols, ldy) with ldy >= rows, zero padded."""
-    _dev(x, out)
+def transpose(x, ldy=None, out=None, colsum=None):
+    """x: (rows, cols) -> (cols, ldy) with ldy >= rows, zero padded; colsum (cols,) fp32 += column sums of x."""
+    _dev(x, out, colsum)
     rows, cols = x.shape
     ldy = ldy or rows
     if out is None:
         out = torch.empty(cols, ldy, device=x.device, dtype=x.dtype)
-    check(lib().st_transpose(_p(x), _p(out), dt_code(x), rows, cols, x.stride(0), ldy, _stream()), "st_transpose")
+    check(lib().st_transpose_colsum(_p(x), _p(out), _p(colsum), dt_code(x), rows, cols, x.stride(0), ldy, _stream()),
+          "st_transpose_colsum")
     return out
 
 

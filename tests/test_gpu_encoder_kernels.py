@@ -278,6 +278,12 @@ def test_layout_and_pool_kernels(dtype):
     assert tt.shape == (130, 80)
     assert torch.equal(tt[:, :77].cpu(), t.cpu().t())
     assert float(tt[:, 77:].float().abs().max()) == 0.0
+    for rows, cols, ldy in [(1857, 1536, 1864), (300, 10000, 304), (5, 12, 8), (128, 70, 128)]:
+        big = torch.randn(rows, cols, generator=g).to("cuda", dtype)
+        cs = torch.full((cols,), 2.0, device="cuda")
+        bt = ops.transpose(big, ldy=ldy, colsum=cs)
+        assert torch.equal(bt[:, :rows].cpu(), big.cpu().t()) and float(bt[:, rows:].float().abs().max() if ldy > rows else 0) == 0.0
+        np.testing.assert_allclose(cs.cpu().numpy(), 2.0 + big.float().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
     c = ops.cast(t, torch.float32)
     assert torch.equal(c.cpu(), t.float().cpu())
 
