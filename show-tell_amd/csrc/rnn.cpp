@@ -5,13 +5,18 @@
 // backward torch builds for it (main.py:151).  Rows are time-major packed exactly as
 // pack_padded_sequence orders them: row(t, b) = step_off[t] + b for b < batch_sizes[t].
 //
+// Both passes walk the (layer, time) grid by DIAGONALS: cell (l, t) needs (l-1, t) and (l, t-1) [forward] or
+// (l+1, t) and (l, t+1) [backward], so the cells with l + t = d are independent and go out as ONE launch
+// (blockIdx.z = cell).  A 5-layer, 18-step caption batch is 22 dependent launches instead of 90: the recurrence
+// is launch-latency bound (a cell is ~0.2 GFLOP), so the count of dependent launches is what it costs.
+//
 // forward:  x0 = [feat ; emb(caption)] gathered straight into packed rows (no cat/pack copies)
-//           per layer: one MFMA GEMM for all timesteps' input projections, then one fused
-//           launch per timestep (h W_hh^T + gates)            -> st_rnn_forward
+//           per diagonal one fused launch: x W_ih^T + h W_hh^T + gates for every cell -> st_rnn_forward
 //           logits = y_top W_lin^T + b
-// backward: dlogits -> dW_lin, db_lin, dy_top; per layer (top down) one gate-gradient kernel +
-//           one skinny GEMM per timestep, then three MFMA GEMMs (dW_ih, dW_hh, dx) whose
-//           K-major operands are produced by explicit transposes -> st_rnn_backward
+// backward: dlogits -> dW_lin, db_lin, dy_top; per diagonal (reversed) one gate-gradient launch and one skinny-GEMM
+//           launch (dh_{t-1} += dgh_t W_hh and dx_t = dgx_t W_ih of every cell); then per layer two MFMA GEMMs
+//           (dW_ih, dW_hh) whose K-major operands come from transposes that also sum the bias gradients
+//           -> st_rnn_backward
 #include "common.h"
 #include "rnn_kernels.h"
 #include <string.h>
@@ -25,7 +30,7 @@ inline int up8(int v) { return (v + 7) & ~7; }
 struct Plan {
   int G, GH, Np, Vp, maxw;
   size_t es;
-  size_t x0, y, gates, cst, gx, dy0, dy1, dgx, dgh, dhc, dcc, hprev, tA, tB, wT, total;
+  size_t x0, y, gates, cst, dyl, dx0, dgx, dgh, dhc, dcc, hprev, tA, tB, wT, wThh, wTih, total;
 };
 
 Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
@@ -43,13 +48,12 @@ Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
   q.y = take(L * n * H * q.es);
   q.gates = take(L * n * 4 * H * q.es);
   q.cst = take(p->cell == ST_CELL_LSTM ? L * n * H * q.es : 0);
-  q.gx = take(n * q.GH * q.es);
-  q.dy0 = take(n * q.maxw * sizeof(float));
-  q.dy1 = take(n * q.maxw * sizeof(float));
-  q.dgx = take(n * q.GH * q.es);
-  q.dgh = take(n * q.GH * q.es);
-  q.dhc = take((size_t)s->B * H * sizeof(float));
-  q.dcc = take((size_t)s->B * H * sizeof(float));
+  q.dyl = take(L * n * H * sizeof(float));          // d loss / d y_l, one [ntok][H] fp32 matrix per layer
+  q.dx0 = take(n * p->in0 * sizeof(float));         // d loss / d x0
+  q.dgx = take(L * n * q.GH * q.es);                // gate gradients of every layer (operands of the dW GEMMs)
+  q.dgh = take(p->cell == ST_CELL_GRU ? L * n * q.GH * q.es : 0);
+  q.dhc = take(L * (size_t)s->B * H * sizeof(float));
+  q.dcc = take(L * (size_t)s->B * H * sizeof(float));
   q.hprev = take(n * H * q.es);
   // transposed operands: tA <= max(V, GH) x Np ; tB <= max(H, in0) x Np ; wT <= max(H x Vp, maxw x GH)
   const size_t ra = (size_t)(p->V > q.GH ? p->V : q.GH);
@@ -57,6 +61,8 @@ Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
   q.tB = take((size_t)q.maxw * q.Np * q.es);
   const size_t w1 = (size_t)H * q.Vp, w2 = (size_t)q.maxw * q.GH;
   q.wT = take((w1 > w2 ? w1 : w2) * q.es);
+  q.wThh = take(L * H * q.GH * q.es);               // W_hh^T and W_ih^T of every layer: the backward wavefront needs them all
+  q.wTih = take(L * (size_t)q.maxw * q.GH * q.es);
   q.total = o;
   return q;
 }
@@ -121,31 +127,34 @@ extern "C" int st_rnn_forward(const st_rnn_params* p, const st_packed_seq* s, co
   std::vector<int> off(s->T + 1, 0);
   for (int t = 0; t < s->T; ++t) off[t + 1] = off[t] + s->batch_sizes_host[t];
 
-  for (int l = 0; l < p->L; ++l) {
-    const void* xl = l == 0 ? x0 : ws + q.y + (size_t)(l - 1) * n * H * es;
-    const int in = l == 0 ? p->in0 : H;
-    char* yl = ws + q.y + (size_t)l * n * H * es;
-    char* gl = ws + q.gates + (size_t)l * n * 4 * H * es;
-    char* cl = ws + q.cst + (size_t)l * n * H * es;
-    if (gemm_nt(xl, in, p->w_ih[l], in, ws + q.gx, q.GH, n, q.GH, in, dt, dt, p->b_ih[l], 0, stream)) return 1;
-    for (int t = 0; t < s->T; ++t) {
+  const int L = p->L, T = s->T;
+  for (int d = 0; d < T + L - 1; ++d) {
+    RnnGemmArgs cells[ST_MAX_LAYERS];
+    int nc = 0;
+    for (int l = d < T ? 0 : d - (T - 1); l <= d && l < L; ++l) {
+      const int t = d - l;
       const int bt = s->batch_sizes_host[t];
-      RnnGemmArgs a;
+      const char* xl = l == 0 ? reinterpret_cast<const char*>(x0) : ws + q.y + (size_t)(l - 1) * n * H * es;
+      const int in = l == 0 ? p->in0 : H;
+      char* yl = ws + q.y + (size_t)l * n * H * es;
+      char* gl = ws + q.gates + (size_t)l * n * 4 * H * es;
+      char* cl = ws + q.cst + (size_t)l * n * H * es;
+      RnnGemmArgs& a = cells[nc++];
       memset(&a, 0, sizeof(a));
       a.M = bt; a.N = H; a.K = H; a.lda = H; a.ldw = H; a.gstride = H;
       a.W = p->w_hh[l];
       a.A = t > 0 ? yl + (size_t)off[t - 1] * H * es : nullptr;
       a.hprev = a.A; a.ldhp = H;
       a.bias_h = p->b_hh[l];
-      a.gx = ws + q.gx + (size_t)off[t] * q.GH * es; a.ldgx = q.GH;
+      a.A2 = xl + (size_t)off[t] * in * es; a.K2 = in; a.lda2 = in; a.W2 = p->w_ih[l]; a.ldw2 = in; a.bias_x = p->b_ih[l];
       a.hout = yl + (size_t)off[t] * H * es; a.ldho = H;
       if (save_for_backward) { a.cache = gl + (size_t)off[t] * 4 * H * es; a.ldcache = 4 * H; }
       if (p->cell == ST_CELL_LSTM) {
         a.cprev = t > 0 ? cl + (size_t)off[t - 1] * H * es : nullptr;
         a.cout = cl + (size_t)off[t] * H * es;
       }
-      if (rnn_gemm_launch(a, dt, p->cell == ST_CELL_GRU ? 1 : 2, 0, st)) return 1;
     }
+    if (rnn_gemm_launch_batch(cells, nc, dt, p->cell == ST_CELL_GRU ? 1 : 2, 1, st)) return 1;
   }
   if (logits) {
     ST_CHECK(p->w_lin && p->b_lin, "st_rnn_forward: logits requested without the vocabulary projection");
@@ -168,8 +177,9 @@ extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, co
   const size_t es = q.es;
   std::vector<int> off(s->T + 1, 0);
   for (int t = 0; t < s->T; ++t) off[t + 1] = off[t] + s->batch_sizes_host[t];
-  float* dy = reinterpret_cast<float*>(ws + q.dy0);
-  float* dx = reinterpret_cast<float*>(ws + q.dy1);
+  const int L = p->L, T = s->T;
+  auto dyl = [&](int l) { return reinterpret_cast<float*>(ws + q.dyl) + (size_t)l * n * H; };   // d loss / d y_l
+  float* dy = dyl(L - 1);
   const char* ytop = ws + q.y + (size_t)(p->L - 1) * n * H * es;
 
   if (dlogits) {
@@ -190,63 +200,79 @@ extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, co
   }
 
   const void* x0 = x0_override ? x0_override : ws + q.x0;
-  for (int l = p->L - 1; l >= 0; --l) {
+  const bool need_dx0 = dfeat || dx0_out || g->emb;
+  float* dx0 = dx0_out ? dx0_out : reinterpret_cast<float*>(ws + q.dx0);
+  const bool gru = p->cell == ST_CELL_GRU;
+  auto dgxl = [&](int l) { return ws + q.dgx + (size_t)l * n * GH * es; };
+  auto dghl = [&](int l) { return gru ? ws + q.dgh + (size_t)l * n * GH * es : dgxl(l); };   // LSTM: one gradient feeds both projections
+  auto dhcl = [&](int l) { return reinterpret_cast<float*>(ws + q.dhc) + (size_t)l * s->B * H; };
+  auto dccl = [&](int l) { return reinterpret_cast<float*>(ws + q.dcc) + (size_t)l * s->B * H; };
+  auto wThh = [&](int l) { return ws + q.wThh + (size_t)l * H * GH * es; };
+  auto wTih = [&](int l) { return ws + q.wTih + (size_t)l * q.maxw * GH * es; };
+  if (hipMemsetAsync(ws + q.dhc, 0, (size_t)L * s->B * H * sizeof(float), st) != hipSuccess ||
+      hipMemsetAsync(ws + q.dcc, 0, (size_t)L * s->B * H * sizeof(float), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
+  for (int l = 0; l < L; ++l) {
+    const int in = l == 0 ? p->in0 : H;
+    // K-major operands of dh_{t-1} += dgh_t W_hh  and  dx_t = dgx_t W_ih
+    if (st_transpose(p->w_hh[l], wThh(l), dt, GH, H, H, GH, stream)) return 1;
+    if ((l > 0 || need_dx0) && st_transpose(p->w_ih[l], wTih(l), dt, GH, in, in, GH, stream)) return 1;
+  }
+  // reversed wavefront: the cells of a diagonal need only cells of the diagonal above
+  for (int d = T + L - 2; d >= 0; --d) {
+    RnnBwdCell gc[ST_MAX_LAYERS];
+    RnnGemmArgs mc[2 * ST_MAX_LAYERS];
+    int ng = 0, nm = 0;
+    for (int l = d < T ? 0 : d - (T - 1); l <= d && l < L; ++l) {
+      const int t = d - l;
+      const int bt = s->batch_sizes_host[t];
+      const int in = l == 0 ? p->in0 : H;
+      char* yl = ws + q.y + (size_t)l * n * H * es;
+      char* gl = ws + q.gates + (size_t)l * n * 4 * H * es;
+      char* cl = ws + q.cst + (size_t)l * n * H * es;
+      RnnBwdCell& c = gc[ng++];
+      memset(&c, 0, sizeof(c));
+      c.dy = dyl(l) + (size_t)off[t] * H; c.dhc = dhcl(l); c.dcc = dccl(l);
+      c.cache = gl + (size_t)off[t] * 4 * H * es;
+      c.hprev = t > 0 ? yl + (size_t)off[t - 1] * H * es : nullptr;
+      c.cnew = cl + (size_t)off[t] * H * es;
+      c.cprev = t > 0 ? cl + (size_t)off[t - 1] * H * es : nullptr;
+      c.dgx = dgxl(l) + (size_t)off[t] * GH * es; c.dgh = dghl(l) + (size_t)off[t] * GH * es; c.Bt = bt;
+      if (t > 0) {                                 // dh_{t-1} += dgh_t W_hh
+        RnnGemmArgs& a = mc[nm++];
+        memset(&a, 0, sizeof(a));
+        a.A = dghl(l) + (size_t)off[t] * GH * es; a.W = wThh(l); a.M = bt; a.N = H; a.K = GH; a.lda = GH; a.ldw = GH;
+        a.out_f32 = dhcl(l); a.ldo = H; a.accumulate = 1;
+      }
+      if (l > 0 || need_dx0) {                     // dx_t = dgx_t W_ih: the gradient the layer below reads at this step
+        RnnGemmArgs& a = mc[nm++];
+        memset(&a, 0, sizeof(a));
+        a.A = dgxl(l) + (size_t)off[t] * GH * es; a.W = wTih(l); a.M = bt; a.N = in; a.K = GH; a.lda = GH; a.ldw = GH;
+        a.out_f32 = (l > 0 ? dyl(l - 1) + (size_t)off[t] * H : dx0 + (size_t)off[t] * in); a.ldo = in;
+      }
+    }
+    if (rnn_bwd_gates_launch_batch(gc, ng, H, p->cell, dt, st)) return 1;
+    if (rnn_gemm_launch_batch(mc, nm, dt, 0, 0, st)) return 1;
+  }
+  // parameter gradients, one layer at a time over all its tokens
+  for (int l = L - 1; l >= 0; --l) {
     const int in = l == 0 ? p->in0 : H;
     const char* xl = l == 0 ? reinterpret_cast<const char*>(x0) : ws + q.y + (size_t)(l - 1) * n * H * es;
     char* yl = ws + q.y + (size_t)l * n * H * es;
-    char* gl = ws + q.gates + (size_t)l * n * 4 * H * es;
-    char* cl = ws + q.cst + (size_t)l * n * H * es;
-    float* dhc = reinterpret_cast<float*>(ws + q.dhc);
-    float* dcc = reinterpret_cast<float*>(ws + q.dcc);
-    if (hipMemsetAsync(dhc, 0, (size_t)s->B * H * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(dcc, 0, (size_t)s->B * H * sizeof(float), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
-    // W_hh^T [H][GH]: K-major operand of dh_{t-1} += dgh_t W_hh
-    if (st_transpose(p->w_hh[l], ws + q.wT, dt, GH, H, H, GH, stream)) return 1;
-    char* dgx = ws + q.dgx;
-    char* dgh = p->cell == ST_CELL_GRU ? ws + q.dgh : ws + q.dgx;   // LSTM: the same gradient feeds both projections
-    for (int t = s->T - 1; t >= 0; --t) {
-      const int bt = s->batch_sizes_host[t];
-      const void* hprev = t > 0 ? yl + (size_t)off[t - 1] * H * es : nullptr;
-      if (p->cell == ST_CELL_GRU) {
-        if (gru_bwd_gates_launch(dy + (size_t)off[t] * H, dhc, gl + (size_t)off[t] * 4 * H * es, hprev,
-                                 dgx + (size_t)off[t] * GH * es, dgh + (size_t)off[t] * GH * es, bt, H, dt, st)) return 1;
-      } else {
-        const void* cprev = t > 0 ? cl + (size_t)off[t - 1] * H * es : nullptr;
-        if (lstm_bwd_gates_launch(dy + (size_t)off[t] * H, dhc, dcc, gl + (size_t)off[t] * 4 * H * es,
-                                  cl + (size_t)off[t] * H * es, cprev, dgx + (size_t)off[t] * GH * es, bt, H, dt, st)) return 1;
-      }
-      if (t > 0) {
-        RnnGemmArgs a;
-        memset(&a, 0, sizeof(a));
-        a.A = dgh + (size_t)off[t] * GH * es; a.W = ws + q.wT; a.M = bt; a.N = H; a.K = GH; a.lda = GH; a.ldw = GH; a.gstride = 0;
-        a.out_f32 = dhc; a.ldo = H; a.accumulate = 1;
-        if (rnn_gemm_launch(a, dt, 0, 0, st)) return 1;
-      }
-    }
-    // parameter gradients of this layer
+    char* dgx = dgxl(l);
+    char* dgh = dghl(l);
     // bias gradients ride on the K-major copies (column sums of the tile already in LDS)
-    if (p->cell != ST_CELL_GRU && colsum_launch(dgh, g->b_hh[l], n, GH, GH, dt, st)) return 1;   // LSTM: dgh == dgx, transposed once
+    if (!gru && colsum_launch(dgh, g->b_hh[l], n, GH, GH, dt, st)) return 1;   // LSTM: dgh == dgx, transposed once
     if (st_transpose_colsum(dgx, ws + q.tA, g->b_ih[l], dt, n, GH, GH, Np, stream)) return 1;
     if (st_transpose(xl, ws + q.tB, dt, n, in, in, Np, stream)) return 1;
     if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_ih[l], in, GH, in, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
     if (gather_hprev_launch(yl, s->rows_t, s->prev_row, ws + q.hprev, n, H, dt, st)) return 1;
-    if (p->cell == ST_CELL_GRU && st_transpose_colsum(dgh, ws + q.tA, g->b_hh[l], dt, n, GH, GH, Np, stream)) return 1;
+    if (gru && st_transpose_colsum(dgh, ws + q.tA, g->b_hh[l], dt, n, GH, GH, Np, stream)) return 1;
     if (st_transpose(ws + q.hprev, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
     if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_hh[l], H, GH, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
-    // dx_l = dgx W_ih  -> gradient w.r.t. the layer below (fp32)
-    if (l > 0 || dfeat || dx0_out || g->emb) {
-      if (st_transpose(p->w_ih[l], ws + q.wT, dt, GH, in, in, GH, stream)) return 1;
-      float* dst = (l == 0 && dx0_out) ? dx0_out : dx;
-      if (gemm_nt(dgx, GH, ws + q.wT, GH, dst, in, n, in, GH, dt, ST_F32, nullptr, 0, stream)) return 1;
-      if (l == 0) {
-        if (!x0_override) {
-          ST_CHECK(g->emb, "st_rnn_backward: embedding gradient buffer missing");
-          if (embedding_bwd_launch(dst, s->caption, s->Tcap, s->rows_b, s->rows_t, dfeat, g->emb, n, p->E, p->V, 0, st)) return 1;
-        }
-      } else {
-        float* tmp = dy; dy = dx; dx = tmp;
-      }
-    }
+  }
+  if (need_dx0 && !x0_override) {
+    ST_CHECK(g->emb, "st_rnn_backward: embedding gradient buffer missing");
+    if (embedding_bwd_launch(dx0, s->caption, s->Tcap, s->rows_b, s->rows_t, dfeat, g->emb, n, p->E, p->V, 0, st)) return 1;
   }
   return 0;
 }

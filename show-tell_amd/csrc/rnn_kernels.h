@@ -18,7 +18,20 @@ struct RnnGemmArgs {
   unsigned long long* argmax_keys;     // EPI 3: per-row packed (value, index) maxima
 };
 
+// Up to kRnnBatch independent cells in ONE launch (blockIdx.z picks the cell): the (layer, time) wavefront of the
+// teacher-forced decoder, where the cells of a diagonal layer + time = d do not depend on each other.
+constexpr int kRnnBatch = 16;
+struct RnnGemmBatch { RnnGemmArgs c[kRnnBatch]; };
+static_assert(sizeof(RnnGemmBatch) <= 4000, "kernel-argument segment is 4 KiB");
+struct RnnBwdCell {                    // BPTT gate gradients of one (layer, time) cell
+  const float* dy; float* dhc; float* dcc; const void* cache; const void* hprev; const void* cnew; const void* cprev;
+  void* dgx; void* dgh; int Bt;
+};
+struct RnnBwdBatch { RnnBwdCell c[kRnnBatch]; };
+
 int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st);
+int rnn_gemm_launch_batch(const RnnGemmArgs* cells, int ncells, int dtype, int epi, int has_x, hipStream_t st);
+int rnn_bwd_gates_launch_batch(const RnnBwdCell* cells, int ncells, int H, int cell_kind, int dtype, hipStream_t st);
 int pack_inputs_launch(const void* feat, const void* emb, const long* cap, int Tcap, const int* rows_b, const int* rows_t,
                        void* x0, long* target, int ntok, int E, int V, int mode, int dtype, hipStream_t st);
 int embedding_bwd_launch(const float* dx0, const long* cap, int Tcap, const int* rows_b, const int* rows_t,

@@ -14,6 +14,7 @@
 // and the whole gate nonlinearity runs in the epilogue so a timestep is ONE launch.
 #include "common.h"
 #include "rnn_kernels.h"
+#include <string.h>
 
 namespace {
 
@@ -118,14 +119,17 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0,
 // EPI 1: GRU gates (training fwd with precomputed gx, or decode with fused x-projection)
 // EPI 2: LSTM gates
 template <typename T, int NG, int EPI, bool HAS_X>
-__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmArgs a) {
+__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
   // block = 16 rows x 16 units (all NG gates); its 4 waves each take a quarter of K and the partial
   // accumulators meet in LDS: one round of L2 latency per launch instead of four.
+  // blockIdx.z selects one of the launch's independent cells (kernel-argument segment, scalar loads).
+  const RnnGemmArgs& a = batch.c[blockIdx.z];
   __shared__ f32x4 red[3][2 * NG][64];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r16 = lane & 15, q4 = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  if (m0 >= a.M || n0 >= a.N) return;            // the grid is sized for the launch's largest cell
   f32x4 accH[NG], accX[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) { accH[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accX[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -317,9 +321,13 @@ __global__ __launch_bounds__(256) void gather_hprev_kernel(const T* __restrict__
 
 // GRU BPTT gate gradients for the B_t rows of one timestep (see DESIGN.md for the algebra)
 template <typename T>
-__global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const float* __restrict__ dy, float* __restrict__ dhc,
-                                                            const T* __restrict__ cache, const T* __restrict__ hprev,
-                                                            T* __restrict__ dgx, T* __restrict__ dgh, int Bt, int H) {
+__global__ __launch_bounds__(256) void gru_bwd_gates_kernel(RnnBwdBatch batch, int H) {
+  const RnnBwdCell& cl = batch.c[blockIdx.y];
+  const float* __restrict__ dy = cl.dy; float* __restrict__ dhc = cl.dhc;
+  const T* __restrict__ cache = reinterpret_cast<const T*>(cl.cache);
+  const T* __restrict__ hprev = reinterpret_cast<const T*>(cl.hprev);
+  T* __restrict__ dgx = reinterpret_cast<T*>(cl.dgx); T* __restrict__ dgh = reinterpret_cast<T*>(cl.dgh);
+  const int Bt = cl.Bt;
   const int total = Bt * (H / 4);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -351,9 +359,14 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const float* __restr
 
 // LSTM BPTT gate gradients: dg is shared by the x- and h-projections (all four gates are sums)
 template <typename T>
-__global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const float* __restrict__ dy, float* __restrict__ dhc, float* __restrict__ dcc,
-                                                             const T* __restrict__ cache, const T* __restrict__ cnew, const T* __restrict__ cprev,
-                                                             T* __restrict__ dg, int Bt, int H) {
+__global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(RnnBwdBatch batch, int H) {
+  const RnnBwdCell& cl = batch.c[blockIdx.y];
+  const float* __restrict__ dy = cl.dy; float* __restrict__ dhc = cl.dhc; float* __restrict__ dcc = cl.dcc;
+  const T* __restrict__ cache = reinterpret_cast<const T*>(cl.cache);
+  const T* __restrict__ cnew = reinterpret_cast<const T*>(cl.cnew);
+  const T* __restrict__ cprev = reinterpret_cast<const T*>(cl.cprev);
+  T* __restrict__ dg = reinterpret_cast<T*>(cl.dgx);
+  const int Bt = cl.Bt;
   const int total = Bt * (H / 4);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -453,14 +466,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 // ---------------------------------------------------------------------------------------
 // internal launchers (declared in rnn_kernels.h)
 // ---------------------------------------------------------------------------------------
-int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st) {
-  if (a.M <= 0) return 0;
-  ST_CHECK(epi == 3 || a.N % 4 == 0, "rnn_gemm: N=%d must be a multiple of 4", a.N);
+int rnn_gemm_launch_batch(const RnnGemmArgs* cells, int ncells, int dtype, int epi, int has_x, hipStream_t st) {
+  ST_CHECK(ncells >= 0 && ncells <= kRnnBatch, "rnn_gemm: %d cells in one launch (max %d)", ncells, kRnnBatch);
+  RnnGemmBatch b;
+  memset(&b, 0, sizeof(b));
   const int epc = dtype == ST_BF16 ? 8 : 4;
-  ST_CHECK(a.K % epc == 0 && a.lda % epc == 0 && a.ldw % epc == 0, "rnn_gemm: K/lda/ldw must be multiples of %d", epc);
-  if (has_x) ST_CHECK(a.K2 % epc == 0 && a.lda2 % epc == 0 && a.ldw2 % epc == 0, "rnn_gemm: K2/lda2/ldw2 must be multiples of %d", epc);
-  const dim3 grid((a.N + 15) / 16, (a.M + 15) / 16), block(256);
-#define RG(T, NG, EPI, HX) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX>), grid, block, 0, st, a)
+  int nc = 0, maxM = 0, maxN = 0;
+  for (int i = 0; i < ncells; ++i) {
+    const RnnGemmArgs& a = cells[i];
+    if (a.M <= 0) continue;
+    ST_CHECK(epi == 3 || a.N % 4 == 0, "rnn_gemm: N=%d must be a multiple of 4", a.N);
+    ST_CHECK(a.K % epc == 0 && a.lda % epc == 0 && a.ldw % epc == 0, "rnn_gemm: K/lda/ldw must be multiples of %d", epc);
+    if (has_x) ST_CHECK(a.K2 % epc == 0 && a.lda2 % epc == 0 && a.ldw2 % epc == 0, "rnn_gemm: K2/lda2/ldw2 must be multiples of %d", epc);
+    b.c[nc++] = a;
+    if (a.M > maxM) maxM = a.M;
+    if (a.N > maxN) maxN = a.N;
+  }
+  if (nc == 0) return 0;
+  const dim3 grid((maxN + 15) / 16, (maxM + 15) / 16, nc), block(256);
+#define RG(T, NG, EPI, HX) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX>), grid, block, 0, st, b)
   if (dtype == ST_BF16) {
     if (epi == 0) RG(bf16_t, 1, 0, false);
     else if (epi == 3) RG(bf16_t, 1, 3, false);
@@ -473,6 +497,33 @@ int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStre
     else { if (has_x) RG(float, 4, 2, true); else RG(float, 4, 2, false); }
   }
 #undef RG
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st) {
+  return rnn_gemm_launch_batch(&a, 1, dtype, epi, has_x, st);
+}
+
+int rnn_bwd_gates_launch_batch(const RnnBwdCell* cells, int ncells, int H, int cell_kind, int dtype, hipStream_t st) {
+  ST_CHECK(ncells >= 0 && ncells <= kRnnBatch, "rnn_bwd_gates: %d cells in one launch (max %d)", ncells, kRnnBatch);
+  RnnBwdBatch b;
+  memset(&b, 0, sizeof(b));
+  int nc = 0, maxB = 0;
+  for (int i = 0; i < ncells; ++i) {
+    if (cells[i].Bt <= 0) continue;
+    b.c[nc++] = cells[i];
+    if (cells[i].Bt > maxB) maxB = cells[i].Bt;
+  }
+  if (nc == 0) return 0;
+  const dim3 grid((maxB * (H / 4) + 255) / 256, nc);
+  if (cell_kind == ST_CELL_GRU) {
+    if (dtype == ST_BF16) hipLaunchKernelGGL(gru_bwd_gates_kernel<bf16_t>, grid, dim3(256), 0, st, b, H);
+    else hipLaunchKernelGGL(gru_bwd_gates_kernel<float>, grid, dim3(256), 0, st, b, H);
+  } else {
+    if (dtype == ST_BF16) hipLaunchKernelGGL(lstm_bwd_gates_kernel<bf16_t>, grid, dim3(256), 0, st, b, H);
+    else hipLaunchKernelGGL(lstm_bwd_gates_kernel<float>, grid, dim3(256), 0, st, b, H);
+  }
   ST_LAUNCH_CHECK();
   return 0;
 }
@@ -516,22 +567,18 @@ int gather_hprev_launch(const void* y, const int* rows_t, const int* prev_row, v
 
 int gru_bwd_gates_launch(const float* dy, float* dhc, const void* cache, const void* hprev, void* dgx, void* dgh,
                          int Bt, int H, int dtype, hipStream_t st) {
-  if (Bt <= 0) return 0;
-  const int grid = (Bt * (H / 4) + 255) / 256;
-  if (dtype == ST_BF16) hipLaunchKernelGGL(gru_bwd_gates_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, dy, dhc, (const bf16_t*)cache, (const bf16_t*)hprev, (bf16_t*)dgx, (bf16_t*)dgh, Bt, H);
-  else hipLaunchKernelGGL(gru_bwd_gates_kernel<float>, dim3(grid), dim3(256), 0, st, dy, dhc, (const float*)cache, (const float*)hprev, (float*)dgx, (float*)dgh, Bt, H);
-  ST_LAUNCH_CHECK();
-  return 0;
+  RnnBwdCell c;
+  memset(&c, 0, sizeof(c));
+  c.dy = dy; c.dhc = dhc; c.cache = cache; c.hprev = hprev; c.dgx = dgx; c.dgh = dgh; c.Bt = Bt;
+  return rnn_bwd_gates_launch_batch(&c, 1, H, ST_CELL_GRU, dtype, st);
 }
 
 int lstm_bwd_gates_launch(const float* dy, float* dhc, float* dcc, const void* cache, const void* cnew, const void* cprev,
                           void* dg, int Bt, int H, int dtype, hipStream_t st) {
-  if (Bt <= 0) return 0;
-  const int grid = (Bt * (H / 4) + 255) / 256;
-  if (dtype == ST_BF16) hipLaunchKernelGGL(lstm_bwd_gates_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, dy, dhc, dcc, (const bf16_t*)cache, (const bf16_t*)cnew, (const bf16_t*)cprev, (bf16_t*)dg, Bt, H);
-  else hipLaunchKernelGGL(lstm_bwd_gates_kernel<float>, dim3(grid), dim3(256), 0, st, dy, dhc, dcc, (const float*)cache, (const float*)cnew, (const float*)cprev, (float*)dg, Bt, H);
-  ST_LAUNCH_CHECK();
-  return 0;
+  RnnBwdCell c;
+  memset(&c, 0, sizeof(c));
+  c.dy = dy; c.dhc = dhc; c.dcc = dcc; c.cache = cache; c.cnew = cnew; c.cprev = cprev; c.dgx = dg; c.Bt = Bt;
+  return rnn_bwd_gates_launch_batch(&c, 1, H, ST_CELL_LSTM, dtype, st);
 }
 
 int colsum_launch(const void* x, float* out, int rows, int cols, int ldx, int dtype, hipStream_t st) {
