@@ -59,35 +59,46 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x))
 // ---------------------------------------------------------------------------------------
 // skinny GEMM  acc[g][m][n] = sum_k A[m][k] * W[g*gstride + n][k]   (+ optional second pair)
 // ---------------------------------------------------------------------------------------
-template <typename T, int NG, bool HAS_X>
-__device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0, int r16, int q4, int kslice,
-                                           f32x4 (&accH)[NG], f32x4 (&accX)[NG]) {
+template <typename T, int NG, bool HAS_X, int MT>
+__device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int mbase, int n0, int r16, int q4, int kslice,
+                                           f32x4 (&accH)[MT][NG], f32x4 (&accX)[MT][NG]) {
   constexpr int EPC = Mfma<T>::EPC;
   constexpr int UNR = 4;
-  const int m = m0 + r16, n = n0 + r16;
-  const bool mok = m < a.M, nok = n < a.N;
-  // The kernel is latency bound (every fragment comes from L2 exactly once), so bytes in flight per wave are the
-  // lever: K is split over the block's 4 waves and a group of UNR K-steps of BOTH operand pairs (h W_hh and, in
-  // the decode form, x W_ih) is requested before the first MFMA of the group -- one round trip per group.
+  const int n = n0 + r16;
+  const bool nok = n < a.N;
+  // The kernel is latency bound (every fragment comes from L2), so bytes in flight per wave are the lever: K is split
+  // over the block's 4 waves and a group of UNR K-steps of BOTH operand pairs (h W_hh and, in the fused form, x W_ih)
+  // is requested before the first MFMA of the group -- one round trip per group.  With MT > 1 the block covers MT
+  // 16-row tiles with the SAME weight fragments held in registers: the weights, the bulk of the L2 traffic when many
+  // cells run in one launch, are fetched once per MT tiles.
   const bool hasH = a.A != nullptr, hasX = HAS_X && a.A2 != nullptr;
-  const T* AH = reinterpret_cast<const T*>(a.A) + (long)m * a.lda;
   const T* WH = reinterpret_cast<const T*>(a.W) + (long)n * a.ldw;
   const long gsH = (long)a.gstride * a.ldw;
-  const T* AX = reinterpret_cast<const T*>(a.A2) + (long)m * a.lda2;
   const T* WX = reinterpret_cast<const T*>(a.W2) + (long)n * a.ldw2;
   const long gsX = (long)a.gstride * a.ldw2;
+  const T* AH[MT]; const T* AX[MT]; bool mok[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = mbase + t * 16 + r16;
+    mok[t] = m < a.M;
+    AH[t] = reinterpret_cast<const T*>(a.A) + (long)m * a.lda;
+    AX[t] = reinterpret_cast<const T*>(a.A2) + (long)m * a.lda2;
+  }
   const int nsH = hasH ? (a.K + 4 * EPC - 1) / (4 * EPC) : 0, nsX = hasX ? (a.K2 + 4 * EPC - 1) / (4 * EPC) : 0;
   const int spwH = (nsH + 3) / 4, spwX = (nsX + 3) / 4;
   const int begH = kslice * spwH, endH = min(nsH, begH + spwH), begX = kslice * spwX, endX = min(nsX, begX + spwX);
   const int ngroups = max((endH - begH + UNR - 1) / UNR, (endX - begX + UNR - 1) / UNR);
   for (int gi = 0; gi < ngroups; ++gi) {
-    u32x4 fa[UNR], fw[UNR][NG], xa[UNR], xw[UNR][NG];
+    u32x4 fa[MT][UNR], fw[UNR][NG], xa[MT][UNR], xw[UNR][NG];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int sH = begH + gi * UNR + u, kH = (sH * 4 + q4) * EPC;
       const bool okH = sH < endH && kH < a.K;
-      fa[u] = u32x4{0u, 0u, 0u, 0u};
-      if (mok && okH) fa[u] = *reinterpret_cast<const u32x4*>(AH + kH);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        fa[t][u] = u32x4{0u, 0u, 0u, 0u};
+        if (mok[t] && okH) fa[t][u] = *reinterpret_cast<const u32x4*>(AH[t] + kH);
+      }
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         fw[u][g] = u32x4{0u, 0u, 0u, 0u};
@@ -96,8 +107,11 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0,
       if (HAS_X) {
         const int sX = begX + gi * UNR + u, kX = (sX * 4 + q4) * EPC;
         const bool okX = sX < endX && kX < a.K2;
-        xa[u] = u32x4{0u, 0u, 0u, 0u};
-        if (mok && okX) xa[u] = *reinterpret_cast<const u32x4*>(AX + kX);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          xa[t][u] = u32x4{0u, 0u, 0u, 0u};
+          if (mok[t] && okX) xa[t][u] = *reinterpret_cast<const u32x4*>(AX[t] + kX);
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           xw[u][g] = u32x4{0u, 0u, 0u, 0u};
@@ -108,35 +122,40 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int m0, int n0,
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        Mfma<T>::run(fw[u][g], fa[u], accH[g]);
-        if (HAS_X) Mfma<T>::run(xw[u][g], xa[u], accX[g]);
-      }
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          Mfma<T>::run(fw[u][g], fa[t][u], accH[t][g]);
+          if (HAS_X) Mfma<T>::run(xw[u][g], xa[t][u], accX[t][g]);
+        }
   }
 }
 
 // EPI 0: out_f32[m][n] (+)= acc (+bias)         (BPTT dh += dgh W_hh, generic small products)
 // EPI 1: GRU gates (training fwd with precomputed gx, or decode with fused x-projection)
 // EPI 2: LSTM gates
-template <typename T, int NG, int EPI, bool HAS_X>
+template <typename T, int NG, int EPI, bool HAS_X, int MT>
 __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
-  // block = 16 rows x 16 units (all NG gates); its 4 waves each take a quarter of K and the partial
-  // accumulators meet in LDS: one round of L2 latency per launch instead of four.
-  // blockIdx.z selects one of the launch's independent cells (kernel-argument segment, scalar loads).
+  // block = MT x 16 rows x 16 units (all NG gates); its 4 waves each take a quarter of K and the partial
+  // accumulators meet in LDS: one round of L2 latency per launch instead of four.  Wave t < MT then runs the
+  // epilogue of row tile t.  blockIdx.z selects one of the launch's independent cells (kernel-argument segment).
   const RnnGemmArgs& a = batch.c[blockIdx.z];
-  __shared__ f32x4 red[3][2 * NG][64];
+  __shared__ f32x4 red[4][MT][2 * NG][64];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r16 = lane & 15, q4 = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-  if (m0 >= a.M || n0 >= a.N) return;            // the grid is sized for the launch's largest cell
-  f32x4 accH[NG], accX[NG];
+  const int n0 = blockIdx.x * 16, mbase = blockIdx.y * 16 * MT;
+  if (mbase >= a.M || n0 >= a.N) return;            // the grid is sized for the launch's largest cell
+  const int m0 = mbase + (wid < MT ? wid : 0) * 16;  // the row tile whose epilogue this wave owns
+  f32x4 accH[MT][NG], accX[MT][NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) { accH[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accX[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  // wave 0 owns the epilogue: its operands (biases, precomputed x-projection, previous state) are requested
-  // BEFORE the fragment loads so that they arrive under the same round trip
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { accH[t][g] = f32x4{0.f, 0.f, 0.f, 0.f}; accX[t][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // the epilogue operands (biases, precomputed x-projection, previous state) are requested BEFORE the fragment loads
+  // so that they arrive under the same round trip
   const int pm = m0 + r16, pn = n0 + 4 * q4;
-  const bool epi_ok = wid == 0 && pm < a.M && pn < a.N && EPI != 3;
+  const bool epi_ok = wid < MT && pm < a.M && pn < a.N && EPI != 3;
   float ex[NG][4], eb[NG][4], es[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < NG; ++g)
@@ -157,20 +176,24 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
       if (prev) load4<T>(reinterpret_cast<const T*>(prev) + (long)pm * a.ldhp + pn, es);
     }
   }
-  skinny_mma<T, NG, HAS_X>(a, m0, n0, r16, q4, wid, accH, accX);
-  if (wid > 0) {
+  skinny_mma<T, NG, HAS_X, MT>(a, mbase, n0, r16, q4, wid, accH, accX);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) { red[wid - 1][g][lane] = accH[g]; if (HAS_X) red[wid - 1][NG + g][lane] = accX[g]; }
-  }
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { red[wid][t][g][lane] = accH[t][g]; if (HAS_X) red[wid][t][NG + g][lane] = accX[t][g]; }
   __syncthreads();
-  if (wid > 0) return;
+  if (wid >= MT) return;
+  f32x4 sumH[NG], sumX[NG];
 #pragma unroll
-  for (int w = 0; w < 3; ++w)
+  for (int g = 0; g < NG; ++g) {
+    sumH[g] = red[0][wid][g][lane];
+    if (HAS_X) sumX[g] = red[0][wid][NG + g][lane];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      accH[g] += red[w][g][lane];
-      if (HAS_X) accX[g] += red[w][NG + g][lane];
+    for (int w = 1; w < 4; ++w) {
+      sumH[g] += red[w][wid][g][lane];
+      if (HAS_X) sumX[g] += red[w][wid][NG + g][lane];
     }
+  }
 
   // lane owns row m = m0 + r16 and units n = n0 + 4*q4 + {0..3}
   const int m = m0 + r16, n = n0 + 4 * q4;
@@ -182,7 +205,7 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (n + e < a.N) {
-        const float v = accH[0][e] + (a.bias_h ? a.bias_h[n + e] : 0.f);
+        const float v = sumH[0][e] + (a.bias_h ? a.bias_h[n + e] : 0.f);
         if (v > best) { best = v; bi = n + e; }
       }
     }
@@ -203,7 +226,7 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
     float* o = a.out_f32 + (long)m * a.ldo + n;
     float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = accH[0][e] + eb[0][e] + es[e];
+    for (int e = 0; e < 4; ++e) v[e] = sumH[0][e] + eb[0][e] + es[e];
     *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
   } else if (EPI == 1) {
     // r,z,n order (torch.nn.GRU): r = s(xr+hr), z = s(xz+hz), n = tanh(xn + r*(hn)), h' = (1-z) n + z h
@@ -212,12 +235,12 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xg[g][e] = (HAS_X ? accX[g][e] : 0.f) + ex[g][e];
+      for (int e = 0; e < 4; ++e) xg[g][e] = (HAS_X ? sumX[g][e] : 0.f) + ex[g][e];
     float hn[4], r[4], z[4], nn[4], hnew[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float hr = accH[0][e] + eb[0][e], hz = accH[1][e] + eb[1][e];
-      hn[e] = accH[2][e] + eb[2][e];
+      const float hr = sumH[0][e] + eb[0][e], hz = sumH[1][e] + eb[1][e];
+      hn[e] = sumH[2][e] + eb[2][e];
       r[e] = sigm(xg[0][e] + hr);
       z[e] = sigm(xg[1][e] + hz);
       nn[e] = tanhf(xg[2][e] + r[e] * hn[e]);
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pre[g][e] = (HAS_X ? accX[g][e] : 0.f) + ex[g < NG ? g : 0][e] + accH[g < NG ? g : 0][e] + eb[g < NG ? g : 0][e];
+      for (int e = 0; e < 4; ++e) pre[g][e] = (HAS_X ? sumX[g][e] : 0.f) + ex[g < NG ? g : 0][e] + sumH[g < NG ? g : 0][e] + eb[g < NG ? g : 0][e];
     float ig[4], fg[4], gg[4], og[4], cn[4], hnew[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -484,7 +507,11 @@ int rnn_gemm_launch_batch(const RnnGemmArgs* cells, int ncells, int dtype, int e
   }
   if (nc == 0) return 0;
   const dim3 grid((maxN + 15) / 16, (maxM + 15) / 16, nc), block(256);
-#define RG(T, NG, EPI, HX) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX>), grid, block, 0, st, b)
+  // many cells in one launch: the weights are most of the L2 traffic -> two row tiles per block share them
+  const bool mt2 = nc >= 2 && maxM > 16 && epi != 3;
+  const dim3 grid2((maxN + 15) / 16, (maxM + 31) / 32, nc);
+#define RG(T, NG, EPI, HX) do { if (mt2) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX, 2>), grid2, block, 0, st, b); \
+                               else hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX, 1>), grid, block, 0, st, b); } while (0)
   if (dtype == ST_BF16) {
     if (epi == 0) RG(bf16_t, 1, 0, false);
     else if (epi == 3) RG(bf16_t, 1, 3, false);
