@@ -202,6 +202,100 @@ __global__ __launch_bounds__(256) void vocab_argmax_kernel(const T* __restrict__
   }
 }
 
+// Same product, LDS-staged form for the shapes that fit (rows*K*sizeof(T) <= 128 KiB per pass, K <= 16 MFMA steps):
+// the block stages ALL activation rows in LDS once (XOR-swizzled 16-byte chunks, conflict-free fragment reads), wave w
+// keeps the weight fragments of ITS 16 vocabulary entries in registers and sweeps the row tiles from LDS.  The
+// projection matrix leaves L2 once chip-wide and the activations once per block -- the fragment-direct kernel above
+// re-reads both 8x through L2 (160 MB per step at B = 128, V = 10000), which is all of its 25 us.
+template <typename T>
+__global__ __launch_bounds__(256) void vocab_argmax_lds_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                               const float* __restrict__ bias, int M, int N, int K,
+                                                               unsigned long long* __restrict__ keys, int rows_per_pass) {
+  constexpr int EPC = MfmaD<T>::EPC, KS = 16;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  unsigned long long* wbest = reinterpret_cast<unsigned long long*>(lds + (size_t)rows_per_pass * K * sizeof(T));   // [4][rows_per_pass]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wid) * 16;
+  const int nr = n0 + r16;
+  const bool nok = nr < N;
+  const T* Wr = W + (long)nr * ldw;
+  u32x4 fw[KS];
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    const int k = (u * 4 + q4) * EPC;
+    fw[u] = u32x4{0u, 0u, 0u, 0u};
+    if (nok && k < K) fw[u] = *reinterpret_cast<const u32x4*>(Wr + k);
+  }
+  const int n = n0 + 4 * q4;                            // lane: entries n .. n+3 of its row
+  float bz[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bz[e] = n + e < N ? bias[n + e] : 0.f;
+  const int cpr = K / EPC;                              // 16-byte chunks per row (multiple of 8: host check)
+  const int rowb = K * (int)sizeof(T);
+  for (int mb = 0; mb < M; mb += rows_per_pass) {
+    const int rows = min(rows_per_pass, M - mb);
+    __syncthreads();                                    // previous pass has left the buffer
+    // 8 chunks per thread in flight: the staging pass is one or two L2 round trips, not one per chunk
+    for (int i0 = threadIdx.x; i0 < rows_per_pass * cpr; i0 += 256 * 8) {
+      u32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * 256, row = i / cpr, c = i - row * cpr;
+        v[j] = u32x4{0u, 0u, 0u, 0u};
+        if (i < rows_per_pass * cpr && row < rows) v[j] = *reinterpret_cast<const u32x4*>(A + (long)(mb + row) * lda + c * EPC);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * 256, row = i / cpr, c = i - row * cpr;
+        if (i < rows_per_pass * cpr) *reinterpret_cast<u32x4*>(lds + row * rowb + ((c ^ (row & 7)) << 4)) = v[j];
+      }
+    }
+    __syncthreads();
+    const int ntile = (rows + 15) / 16;
+    for (int mt = 0; mt < ntile; ++mt) {
+      const int row = mt * 16 + r16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {
+        if (u * 4 * EPC < K) {
+          const u32x4 fa = *reinterpret_cast<const u32x4*>(lds + row * rowb + (((u * 4 + q4) ^ (row & 7)) << 4));
+          MfmaD<T>::run(fw[u], fa, acc);
+        }
+      }
+      float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e < N) {
+          const float v = acc[e] + bz[e];
+          if (v > best || (v == best && n + e < bi)) { best = v; bi = n + e; }
+        }
+      }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (q4 == 0) {
+        unsigned long long key = 0ull;                  // 0 = nothing (real keys have a non-zero index half)
+        if (bi != 0x7fffffff) {
+          unsigned u = __float_as_uint(best);
+          u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+          key = ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi);
+        }
+        wbest[wid * rows_per_pass + row] = key;
+      }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      unsigned long long k = wbest[r];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { const unsigned long long o = wbest[w * rows_per_pass + r]; k = o > k ? o : k; }
+      if (k) atomicMax(keys + mb + r, k);
+    }
+  }
+}
+
 // packed (value, index) maxima -> token ids of step t, next-step embedding rows; keys are re-armed (0) for the next step
 template <typename T>
 __global__ __launch_bounds__(256) void keys_to_ids_embed_kernel(unsigned long long* __restrict__ keys, long* __restrict__ ids,
@@ -278,13 +372,32 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
     }
     if (!logits_out) {
       // fast path: vocabulary projection with a fused running arg-max (the logits are never written)
-      const int nsl = (V + 127) / 128, nmt = (B + 15) / 16;
-      const dim3 vgrid(((nsl + 7) / 8) * 8 * nmt);
       const char* htop = hbuf[nxt] + (size_t)(L - 1) * B * H * es;
-      if (dt == ST_BF16)
-        hipLaunchKernelGGL(vocab_argmax_kernel<bf16_t>, vgrid, dim3(256), 0, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, keys);
-      else
-        hipLaunchKernelGGL(vocab_argmax_kernel<float>, vgrid, dim3(256), 0, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, keys);
+      const int epc = dt == ST_BF16 ? 8 : 4;
+      int rpp = (int)((128 * 1024) / ((size_t)H * es)) & ~15;
+      if (rpp > ((B + 15) & ~15)) rpp = (B + 15) & ~15;
+      if (H <= 64 * epc && H % (8 * epc) == 0 && rpp >= 16) {
+        // LDS-staged form: activations once per block, projection matrix once chip-wide
+        const size_t lds = (size_t)rpp * H * es + (size_t)4 * rpp * sizeof(unsigned long long);
+        static bool attr_set = false;
+        if (!attr_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_argmax_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_argmax_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr_set = true;
+        }
+        const dim3 vgrid((V + 63) / 64);
+        if (dt == ST_BF16)
+          hipLaunchKernelGGL(vocab_argmax_lds_kernel<bf16_t>, vgrid, dim3(256), lds, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, keys, rpp);
+        else
+          hipLaunchKernelGGL(vocab_argmax_lds_kernel<float>, vgrid, dim3(256), lds, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, keys, rpp);
+      } else {
+        const int nsl = (V + 127) / 128, nmt = (B + 15) / 16;
+        const dim3 vgrid(((nsl + 7) / 8) * 8 * nmt);
+        if (dt == ST_BF16)
+          hipLaunchKernelGGL(vocab_argmax_kernel<bf16_t>, vgrid, dim3(256), 0, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, keys);
+        else
+          hipLaunchKernelGGL(vocab_argmax_kernel<float>, vgrid, dim3(256), 0, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, keys);
+      }
       ST_LAUNCH_CHECK();
       if (dt == ST_BF16)
         hipLaunchKernelGGL(keys_to_ids_embed_kernel<bf16_t>, dim3(B), dim3(64), 0, st, keys, ids_out, steps, t, (const bf16_t*)p->emb, (bf16_t*)xbuf, E, V);
