@@ -77,6 +77,8 @@ int st_conv(const st_conv_desc* d, void* stream);
  * 1: bf16 128x64, 2: bf16 64x128, 4..6 the same for f32); synchronise the device first. */
 int st_tune(int reserved, int kc, int w8);   /* main-loop variant knobs for tools/bench_conv.py (row chunk count 4|8, block shape); -1 = keep */
 int st_prof_enable(int on);
+/* debug aid: per-block phase timestamps of st_conv launches (tools/conv_stamps.py); NULL = off (default) */
+int st_debug_stamps(unsigned long long* buf);
 int st_prof_collect(double* ms, double* flops, long* launches);
 
 /* ------------------------------------------------------------------------------------

@@ -65,6 +65,7 @@ _SIGS = {
     "st_conv": ([C.POINTER(ConvDesc), c_p], c_i),
     "st_tune": ([c_i, c_i, c_i], c_i),
     "st_prof_enable": ([c_i], c_i),
+    "st_debug_stamps": ([c_p], c_i),
     "st_prof_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_l)], c_i),
     "st_bn_act": ([C.POINTER(BnActDesc), c_p], c_i),
     "st_bn_update_running": ([c_p, c_p, c_p, c_i, c_f, c_f, c_p], c_i),

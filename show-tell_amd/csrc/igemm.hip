@@ -35,6 +35,7 @@ namespace {
 constexpr int kVariants = 8;
 struct ProfRec { hipEvent_t e0, e1; int variant; double flops; };
 bool g_prof_on = false;
+unsigned long long* g_stamps = nullptr;   // st_debug_stamps
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
 constexpr size_t kProfMax = 1 << 16;
@@ -46,6 +47,7 @@ struct IgemmArgs {
   int Hin, Win, Cin, Ho, Wo, KH, KW, stride, pad;
   int ldx, ldw, ldy;
   int relu, accumulate, out_f32, korder, srep;
+  unsigned long long* stamps;   // debug: per-block phase timestamps (tools/conv_stamps.py), normally NULL
   int nbm, nbn;
   double flops;   // algorithmic 2*M*N*K (host side only, profiler)
 };
@@ -79,6 +81,15 @@ template <bool RAWB> __device__ __forceinline__ void epi_barrier() {
   }
 }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4): v_add_f32 with row_ror 8/4/2/1, every lane gets the total
+template <int CTRL> __device__ __forceinline__ float dpp_rot(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_rot<0x128>(v); v += dpp_rot<0x124>(v); v += dpp_rot<0x122>(v); v += dpp_rot<0x121>(v);
+  return v;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool RAWB = false, int SW0 = 0, int SNW = WM * WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
                                                int bm, int bn, int tid) {
@@ -92,8 +103,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
   // lane holds, for tile (i,j): pixel m = m0 + i*16 + r16, channels n = n0 + j*16 + 4*q4 + e
   const int m0 = bm * BM + wm * (BM / WM), n0 = bn * BN + wn * (BN / WN);
 
+  // per-wave statistics partials live BEHIND the staging buffer, so the cross-wave sum shares the first staging barrier
+  float* red = reinterpret_cast<float*>(smem + 64 * (BN + 4) * 4);  // [2][BN][WM]
   if (a.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [2][BN][WM] after the final barrier
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float s[4], ss[4];
@@ -108,9 +120,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
           const float t = (m < a.M) ? acc[i][j][e] + bz : 0.f;
           v += t; v2 += t * t;
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { v += __shfl_xor(v, o, 64); v2 += __shfl_xor(v2, o, 64); }
-        s[e] = v; ss[e] = v2;
+        s[e] = row16_sum(v); ss[e] = row16_sum(v2);   // DPP rotates inside the 16-lane row: plain VALU, no LDS crossbar
       }
       if (r16 == 0) {
 #pragma unroll
@@ -121,18 +131,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         }
       }
     }
-    epi_barrier<RAWB>();
-    float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);   // replica of this pixel tile
-    if (storer) for (int t = stid; t < 2 * BN; t += NT) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) v += red[t * WM + w];
-      const int nl = t < BN ? t : t - BN;
-      const int n = bn * BN + nl;
-      if (n < a.N) atomicAdd(sdst + (t < BN ? n : a.N + n), v);
-    }
   }
 
+  if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
   // ---- staged store: registers -> LDS (fp32, 64-row halves) -> 16-byte coalesced global stores --------
   // Every output row leaves as whole 128-byte lines (8 consecutive channels per lane, 16 lanes per row).
   constexpr int SROW = BN + 4;                       // floats per staged row (+16 B: spreads the banks)
@@ -142,7 +143,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
   const int lrow0 = (wm * (BM / WM)) % 64;           // this wave's first row inside its half
 #pragma unroll
   for (int h = 0; h < HALVES; ++h) {
-    epi_barrier<RAWB>();                              // stats reduction / previous half has left the buffer
+    if (h == 1 && a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
+    if (h > 0) epi_barrier<RAWB>();                   // previous half has left the buffer (the K loop ended on a barrier)
     if (my_half == h) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -164,6 +166,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         }
     }
     epi_barrier<RAWB>();
+    if (h == 0 && a.stats) {                          // the partials of every wave are in `red` now
+      float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);   // replica of this pixel tile
+      if (storer) for (int t = stid; t < 2 * BN; t += NT) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += red[t * WM + w];
+        const int nl = t < BN ? t : t - BN;
+        const int n = bn * BN + nl;
+        if (n < a.N) atomicAdd(sdst + (t < BN ? n : a.N + n), v);
+      }
+    }
     constexpr int CPR = BN / 8;                       // 8-channel chunks per row
     constexpr int RPI = NT / CPR;                     // rows per pass
     const int c8 = (stid % CPR) * 8, rr = stid / CPR;
@@ -261,6 +274,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid - wm * WN;
+#define ST_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  ST_STAMP(0);
 
   // ---- loader state ----------------------------------------------------------------
   // FAST (Cin % BK == 0): every chunk of a K tile lies in ONE filter tap, so the tap walk is block-uniform
@@ -362,9 +377,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   const int r16 = lane & 15, q4 = lane >> 4;
   const int nk = (a.K + BK - 1) / BK;
 
+  ST_STAMP(1);
   gload();
   lstore(0);
   __syncthreads();
+  ST_STAMP(2);
 
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
@@ -389,14 +406,24 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
     __syncthreads();
   }
 
+  ST_STAMP(3);
   igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
+  ST_STAMP(4);
+  if (a.stamps && tid == 0) {
+    unsigned hw;   // HW_ID: which XCC / SE / CU / SIMD this wave ran on
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.stamps[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+  }
+#undef ST_STAMP
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool FAST>
 int launch_(IgemmArgs& a, hipStream_t st) {
   a.nbm = (a.M + BM - 1) / BM;
   a.nbn = (a.N + BN - 1) / BN;
-  constexpr int kloop = 2 * (BM + BN) * KC * 16, stage = 64 * (BN + 4) * 4;
+  constexpr int kloop = 2 * (BM + BN) * KC * 16, stage = 64 * (BN + 4) * 4 + 2 * BN * WM * 4;   // staging rows + statistics partials
   const int lds = kloop > stage ? kloop : stage;
   constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + (BN == 64 ? 1 : (BM == 64 ? 2 : (BM == 256 ? 3 : 0)));
   ProfRec rec; bool prof = false;
@@ -489,7 +516,7 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy;
   a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == ST_F32;
-  a.korder = d->k_order; a.srep = d->stats_replicas;
+  a.korder = d->k_order; a.srep = d->stats_replicas; a.stamps = g_stamps;
   a.flops = 2.0 * a.M * a.N * d->KH * d->KW * (d->Cin_logical > 0 ? d->Cin_logical : d->Cin);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == ST_BF16 ? dispatch<bf16_t>(a, st) : dispatch<float>(a, st);
@@ -502,6 +529,11 @@ extern "C" int st_tune(int ring, int kc, int w8) {
   if (w8 >= 0) g_tune[2] = w8;
   return 0;
 }
+
+// Debug aid (tools/conv_stamps.py): when set, block b of every st_conv launch writes s_memtime at kernel entry, after the
+// address set-up, after the first tile is in LDS, after the K loop and after the epilogue to buf[8*b .. 8*b+4], and its
+// (XCC_ID << 32 | HW_ID) to buf[8*b+5].  NULL (the default) switches it off.
+extern "C" int st_debug_stamps(unsigned long long* buf) { g_stamps = buf; return 0; }
 
 // ---- profiler control (used by bench.py only) -----------------------------------------------
 extern "C" int st_prof_enable(int on) {
