@@ -133,7 +133,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     }
   }
 
-  if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
   // ---- staged store: registers -> LDS (fp32, 64-row halves) -> 16-byte coalesced global stores --------
   // Every output row leaves as whole 128-byte lines (8 consecutive channels per lane, 16 lanes per row).
   constexpr int SROW = BN + 4;                       // floats per staged row (+16 B: spreads the banks)
@@ -143,7 +142,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
   const int lrow0 = (wm * (BM / WM)) % 64;           // this wave's first row inside its half
 #pragma unroll
   for (int h = 0; h < HALVES; ++h) {
-    if (h == 1 && a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
     if (h > 0) epi_barrier<RAWB>();                   // previous half has left the buffer (the K loop ended on a barrier)
     if (my_half == h) {
 #pragma unroll
@@ -276,6 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   const int wm = wid / WN, wn = wid - wm * WN;
 #define ST_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   ST_STAMP(0);
+  if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();   // chip-wide 100 MHz clock at block entry
 
   // ---- loader state ----------------------------------------------------------------
   // FAST (Cin % BK == 0): every chunk of a K tile lies in ONE filter tap, so the tap walk is block-uniform
@@ -415,6 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     a.stamps[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+    a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();   // chip-wide 100 MHz clock at block exit
   }
 #undef ST_STAMP
 }
