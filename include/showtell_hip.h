@@ -68,6 +68,10 @@ typedef struct {
   int Cin_logical;      /* 0 = Cin; the un-padded channel count (profiler FLOP accounting) */
   int k_order;          /* 0: w is [N][KH][KW][Cin]; 1: w is [N][Cin/CH][KH][KW][CH], CH = 128 bytes of channels */
   int stats_replicas;   /* 0/1: stats is [2N]; R > 1: stats is [R][2N] (see above)               */
+  /* Optional input transform (train-mode bottleneck, cnn.py:46): x is the RAW output of the producing conv and the
+   * A operand becomes relu(batchnorm(x)) with batch statistics in_stats = [sum | sumsq] over in_count rows -- the
+   * producer's normalise pass is absorbed by this conv.  Needs Cin % 64 == 0 (bf16) / 32 (f32).  NULL = off. */
+  const float* in_stats; const float* in_gamma; const float* in_beta; float in_count, in_eps;
 } st_conv_desc;
 
 int st_conv(const st_conv_desc* d, void* stream);

@@ -19,7 +19,8 @@ class ConvDesc(C.Structure):
                 ("residual", c_p), ("stats", c_p), ("dtype", c_i), ("out_dtype", c_i),
                 ("B", c_i), ("Hin", c_i), ("Win", c_i), ("Cin", c_i), ("Ho", c_i), ("Wo", c_i), ("N", c_i),
                 ("KH", c_i), ("KW", c_i), ("stride", c_i), ("pad", c_i),
-                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i), ("Cin_logical", c_i), ("k_order", c_i), ("stats_replicas", c_i)]
+                ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i), ("Cin_logical", c_i), ("k_order", c_i), ("stats_replicas", c_i),
+                ("in_stats", c_p), ("in_gamma", c_p), ("in_beta", c_p), ("in_count", c_f), ("in_eps", c_f)]
 
 
 class BnActDesc(C.Structure):

@@ -47,6 +47,7 @@ struct IgemmArgs {
   int Hin, Win, Cin, Ho, Wo, KH, KW, stride, pad;
   int ldx, ldw, ldy;
   int relu, accumulate, out_f32, korder, srep;
+  const float* in_stats; const float* in_gamma; const float* in_beta; float in_inv_count, in_eps;   // input BN+ReLU (XF)
   unsigned long long* stamps;   // debug: per-block phase timestamps (tools/conv_stamps.py), normally NULL
   int nbm, nbn;
   double flops;   // algorithmic 2*M*N*K (host side only, profiler)
@@ -247,8 +248,13 @@ template <int KC> __device__ __forceinline__ int swz(int row, int c) {
   return KC == 8 ? (c ^ (row & 7)) : (c ^ ((-(row >> 2)) & 3));
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool FAST>
+// MODE 0: generic tap walk; 1: FAST (whole K tiles inside one tap); 2: FAST + input transform: the A operand is
+// relu(batchnorm(x)) of the producer's raw output, applied between the global load and the LDS write with
+// coefficients derived in the prologue from the producer's statistics -- the consumer conv absorbs the producer's
+// normalise pass (one launch and one read+write of the tensor less per fused pair).
+template <typename T, int BM, int BN, int WM, int WN, int KC, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
+  constexpr bool FAST = MODE >= 1, XF = MODE == 2;
   constexpr int NT = 64 * WM * WN;
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = KC * EPC;               // K elements per tile row (KC chunks = 128 or 64 bytes)
@@ -319,13 +325,18 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   const int ntap = a.KH * a.KW;
 
   u32x4 ra[PA], rb[PB];
+  bool rok[PA];          // XF: row i of the tile in registers was really loaded (padding / ragged rows stay zero)
+  int xf_kc = 0;         // XF: channel offset of the tile in registers
   auto gload = [&]() {
     const bool kok = FAST ? (a.korder ? kc < a.Cin : tap < ntap) : kh < a.KH;
+    if (XF) xf_kc = kc;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (FAST) {
-        if (kok && ((amask[i] >> tap) & 1ull)) v = *reinterpret_cast<const u32x4*>(arow[i] + (tapoff + kc));
+        const bool ok = kok && ((amask[i] >> tap) & 1ull);
+        if (ok) v = *reinterpret_cast<const u32x4*>(arow[i] + (tapoff + kc));
+        if (XF) rok[i] = ok;
       } else {
         const int hi = (hw0[i] >> 16) + kh, wi = (int)(short)(hw0[i] & 0xffff) + kw;
         if (kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win)
@@ -353,8 +364,35 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
       while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
     }
   };
+  constexpr int KLOOP_BYTES = 2 * TILE_BYTES, STAGE_BYTES = 64 * (BN + 4) * 4 + 2 * BN * WM * 4;
+  float* coef = reinterpret_cast<float*>(smem + (KLOOP_BYTES > STAGE_BYTES ? KLOOP_BYTES : STAGE_BYTES));   // XF: [scale(Cin) | shift(Cin)]
   auto lstore = [&](int buf) {
     char* base = smem + buf * TILE_BYTES;
+    if (XF) {
+      float sc[EPC], sh[EPC];
+      const float* cs = coef + xf_kc + ccol * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(cs + e), h4 = *reinterpret_cast<const f32x4*>(cs + a.Cin + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sc[e + q] = s4[q]; sh[e + q] = h4[q]; }
+      }
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        if (!rok[i]) continue;
+        if (sizeof(T) == 2) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const float lo = fmaxf(__uint_as_float(ra[i][d] << 16) * sc[2 * d] + sh[2 * d], 0.f);
+            const float hi = fmaxf(__uint_as_float(ra[i][d] & 0xffff0000u) * sc[2 * d + 1] + sh[2 * d + 1], 0.f);
+            ra[i][d] = pack_bf16x2(lo, hi);
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) ra[i][d] = __float_as_uint(fmaxf(__uint_as_float(ra[i][d]) * sc[d] + sh[d], 0.f));
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int row = lrow + i * RPP;
@@ -378,6 +416,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
 
   ST_STAMP(1);
   gload();
+  if (XF) {   // coefficients of the producer's BatchNorm, while the first tile is in flight
+    const float inv = 1.0f / a.in_inv_count;   // field carries the row count
+    for (int c = tid; c < a.Cin; c += NT) {
+      const float mean = a.in_stats[c] * inv;
+      const float var = fmaxf(a.in_stats[a.Cin + c] * inv - mean * mean, 0.f);
+      const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
+      coef[c] = scv;
+      coef[a.Cin + c] = a.in_beta[c] - mean * scv;
+    }
+    __syncthreads();
+  }
   lstore(0);
   __syncthreads();
   ST_STAMP(2);
@@ -419,12 +468,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
 #undef ST_STAMP
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool FAST>
+template <typename T, int BM, int BN, int WM, int WN, int KC, int MODE>
 int launch_(IgemmArgs& a, hipStream_t st) {
   a.nbm = (a.M + BM - 1) / BM;
   a.nbn = (a.N + BN - 1) / BN;
   constexpr int kloop = 2 * (BM + BN) * KC * 16, stage = 64 * (BN + 4) * 4 + 2 * BN * WM * 4;   // staging rows + statistics partials
-  const int lds = kloop > stage ? kloop : stage;
+  const int lds = (kloop > stage ? kloop : stage) + (MODE == 2 ? 2 * a.Cin * (int)sizeof(float) : 0);
   constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + (BN == 64 ? 1 : (BM == 64 ? 2 : (BM == 256 ? 3 : 0)));
   ProfRec rec; bool prof = false;
   if (g_prof_on) {
@@ -434,13 +483,13 @@ int launch_(IgemmArgs& a, hipStream_t st) {
       (void)hipEventRecord(rec.e0, st);
     }
   }
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, KC, FAST>),
+  static int attr_set = 0;
+  if (attr_set < lds && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, KC, MODE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_set = lds;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, FAST>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, MODE>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
   if (prof) {
     (void)hipEventRecord(rec.e1, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -454,7 +503,11 @@ template <typename T, int BM, int BN, int WM, int WN, int KC>
 int launch(IgemmArgs& a, hipStream_t st) {
   constexpr int BK = KC * (16 / (int)sizeof(T));
   const bool fast = (a.Cin % BK == 0) && a.KH * a.KW <= 64;
-  return fast ? launch_<T, BM, BN, WM, WN, KC, true>(a, st) : launch_<T, BM, BN, WM, WN, KC, false>(a, st);
+  if (a.in_stats) {
+    ST_CHECK(fast, "st_conv: the input transform needs Cin to be a multiple of %d", BK);
+    return launch_<T, BM, BN, WM, WN, KC, 2>(a, st);
+  }
+  return fast ? launch_<T, BM, BN, WM, WN, KC, 1>(a, st) : launch_<T, BM, BN, WM, WN, KC, 0>(a, st);
 }
 
 int g_tune[3] = {-1, -1, -1};   // (unused), kc, w8 (-1: take the environment default)
@@ -517,6 +570,8 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy;
   a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == ST_F32;
   a.korder = d->k_order; a.srep = d->stats_replicas; a.stamps = g_stamps;
+  a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_inv_count = d->in_count;   /* the kernel forms 1/count itself, as bn_act does */ a.in_eps = d->in_eps;
+  ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f && d->ldx >= d->Cin && d->Cin <= 8192), "st_conv: input transform needs gamma, beta, count");
   a.flops = 2.0 * a.M * a.N * d->KH * d->KW * (d->Cin_logical > 0 ? d->Cin_logical : d->Cin);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return d->dtype == ST_BF16 ? dispatch<bf16_t>(a, st) : dispatch<float>(a, st);

@@ -237,8 +237,9 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   int stats_used = 0;   // floats handed out so far
 
   // conv: train -> raw output + statistics; eval -> folded BN (+residual)(+ReLU) in the epilogue
+  // in_ci >= 0 (train): x is the RAW output of conv in_ci; this conv reads relu(bn_{in_ci}(x)) in its loader
   auto conv = [&](int ci, const void* x, int hin, int win, void* y, const void* eval_res, int eval_relu,
-                  int* ho, int* wo) -> int {
+                  int* ho, int* wo, int in_ci = -1) -> int {
     const ConvL& c = r->convs[ci];
     st_conv_desc d;
     memset(&d, 0, sizeof(d));
@@ -252,6 +253,11 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     if (ci == 0 && s2d) {
       d.w = s2dw; d.Hin = hin / 2 + 3; d.Win = win / 2 + 3; d.Cin = 64; d.ldx = 16; d.KH = 4; d.KW = 1; d.stride = 1; d.pad = 0;
       d.ldw = 256; d.Cin_logical = 36;   // 4 rows x 36 = 144 of the 147 real taps: the profiler's FLOP count stays below the algorithmic one
+    }
+    if (train && in_ci >= 0) {
+      const ConvL& pc = r->convs[in_ci];
+      d.in_stats = stats + tab.soff[in_ci]; d.in_gamma = bn_gamma + pc.bnoff; d.in_beta = bn_beta + pc.bnoff;
+      d.in_count = tab.count[in_ci]; d.in_eps = eps;
     }
     if (train) {
       // replicas: keep ~128-256 pixel tiles per replica (same-address atomics serialise), at most kStatsRepFloats per layer
@@ -308,13 +314,16 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
       if (train && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2)) return 1;
-      if (train && bnact(b.c2, narrow[1], (long)B * h2 * w2, 1, nullptr, -1)) return 1;
+      // train: bn2 + relu are applied by conv3's loader (no separate pass over the 3x3 output); needs whole 64-channel
+      // (f32: 32) K tiles, which every bottleneck width satisfies
+      const bool fuse2 = train && r->convs[b.c3].cin % 64 == 0;
+      if (train && !fuse2 && bnact(b.c2, narrow[1], (long)B * h2 * w2, 1, nullptr, -1)) return 1;
       const void* res = xin;
       if (b.ds >= 0) {
         if (conv(b.ds, xin, h, w, wide[dsb], nullptr, 0, &hd, &wd)) return 1;
         res = wide[dsb];
       }
-      if (conv(b.c3, narrow[1], h2, w2, wide[oth], res, 1, &h3, &w3)) return 1;
+      if (conv(b.c3, narrow[1], h2, w2, wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
       if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
     } else {
       if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;

@@ -36,9 +36,11 @@ def _dev(*ts):
 
 
 def conv_nhwc(x, w, KH, KW, stride, pad, out_dtype=None, bias=None, scale=None, shift=None,
-              residual=None, stats=None, relu=False, out=None, accumulate=False, k_order=0, stats_replicas=0):
+              residual=None, stats=None, relu=False, out=None, accumulate=False, k_order=0, stats_replicas=0,
+              in_bn=None):
     """x: (B,Hin,Win,Cin) NHWC; w: (N, KH*KW*Cin) K-contiguous.  Returns (B,Ho,Wo,N).
-    stats_replicas = R > 1: stats is (R, 2N), pixel tile t adds into replica t % R."""
+    stats_replicas = R > 1: stats is (R, 2N), pixel tile t adds into replica t % R.
+    in_bn = dict(stats, gamma, beta, count[, eps]): x is a producer's raw output, the conv reads relu(batchnorm(x))."""
     _dev(x, w, bias, scale, shift, residual, stats, out)
     B, Hin, Win, Cin = x.shape
     N = w.shape[0]
@@ -52,6 +54,10 @@ def conv_nhwc(x, w, KH, KW, stride, pad, out_dtype=None, bias=None, scale=None, 
     d = ConvDesc(_p(x), _p(w), _p(out), _p(bias), _p(scale), _p(shift), _p(residual), _p(stats),
                  dt_code(x), _DT[out_dtype], B, Hin, Win, Cin, Ho, Wo, N, KH, KW, stride, pad,
                  Cin, w.shape[1], N, int(relu), int(accumulate), 0, int(k_order), int(stats_replicas))
+    if in_bn is not None:
+        _dev(in_bn["stats"], in_bn["gamma"], in_bn["beta"])
+        d.in_stats, d.in_gamma, d.in_beta = in_bn["stats"].data_ptr(), in_bn["gamma"].data_ptr(), in_bn["beta"].data_ptr()
+        d.in_count, d.in_eps = float(in_bn["count"]), float(in_bn.get("eps", 1e-5))
     check(lib().st_conv(C.byref(d), _stream()), "st_conv")
     return out
 

@@ -240,6 +240,36 @@ def test_maxpool_bn_equals_two_pass(dtype):
     _close(one, ref, dtype, "bn+relu+maxpool")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(3, 14, 256, 1024, 1), (2, 28, 128, 512, 1), (5, 7, 512, 2048, 1), (2, 14, 64, 64, 3), (1, 9, 128, 96, 3)])
+def test_conv_input_bn_relu_equals_separate_pass(dtype, case):
+    """st_conv_desc.in_stats: the consumer conv applies relu(batchnorm(x)) to the producer's raw output in its loader.
+    Must equal bn_act followed by the plain conv (bf16: bit for bit -- same coefficients, same rounding point; fp32:
+    to an ulp of the normalised input), including the zero padding of a 3x3 consumer (padding taps stay zero, they
+    are not relu(shift))."""
+    ops = _ops()
+    B, H, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(B * H + Cin)
+    x = (torch.randn(B, H, H, Cin, generator=g) * 1.5 + 0.3).to("cuda", dtype)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k))
+    wd = ops.pack_conv_weight(w.cuda(), dtype)
+    gam, bet = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.5).cuda()
+    x2 = x.float().reshape(-1, Cin)
+    stats = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).contiguous()
+    n = B * H * H
+    y_sep = ops.conv_nhwc(ops.bn_act(x, gam, bet, stats=stats, count=n, relu=True), wd, k, k, 1, k // 2)
+    st = torch.zeros(2 * Cout, device="cuda")
+    y_fused = ops.conv_nhwc(x, wd, k, k, 1, k // 2, stats=st, in_bn=dict(stats=stats, gamma=gam, beta=bet, count=n))
+    torch.cuda.synchronize()
+    if dtype == torch.bfloat16:
+        assert torch.equal(y_sep, y_fused)
+    else:
+        assert (y_sep - y_fused).abs().max().item() <= 2e-6 * y_sep.abs().max().item()
+    ref = F.conv2d(F.relu(F.batch_norm(x.float().cpu().permute(0, 3, 1, 2), None, None, gam.cpu(), bet.cpu(), True, 0.1, 1e-5)).to(dtype).float(),
+                   w.to(dtype).float(), None, 1, k // 2).permute(0, 2, 3, 1)
+    _close(y_fused, ref, dtype, "conv(relu(bn(x)))")
+
+
 def test_bn_update_running_matches_torch():
     ops = _ops()
     g = torch.Generator().manual_seed(9)
