@@ -75,6 +75,9 @@ typedef struct {
 } st_conv_desc;
 
 int st_conv(const st_conv_desc* d, void* stream);
+/* n <= 12 independent problems of identical shape, dtype and options (only the pointers differ) as ONE launch: the
+ * per-layer weight-gradient GEMMs of the decoder backward (autograd of nn.GRU, main.py:151) are 48 tiles each. */
+int st_conv_batch(const st_conv_desc* d, int n, void* stream);
 
 /* Launch profiler for bench.py's roofline: HIP events around every st_conv launch on its stream.
  * st_prof_collect fills 8-entry arrays indexed by kernel variant (0: bf16 128x128 tile,

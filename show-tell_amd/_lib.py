@@ -64,6 +64,7 @@ class PackedSeq(C.Structure):
 _SIGS = {
     "st_version": ([], c_i),
     "st_conv": ([C.POINTER(ConvDesc), c_p], c_i),
+    "st_conv_batch": ([C.POINTER(ConvDesc), c_i, c_p], c_i),
     "st_tune": ([c_i, c_i, c_i], c_i),
     "st_prof_enable": ([c_i], c_i),
     "st_debug_stamps": ([c_p], c_i),

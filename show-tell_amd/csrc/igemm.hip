@@ -27,6 +27,7 @@
 #include <vector>
 #include <mutex>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -52,6 +53,12 @@ struct IgemmArgs {
   int nbm, nbn;
   double flops;   // algorithmic 2*M*N*K (host side only, profiler)
 };
+
+// Up to kGroup independent problems of identical shape in ONE launch (blockIdx.y = member): the decoder's ten per-layer
+// weight-gradient GEMMs are 48 tiles each -- alone they leave 80 % of the CUs idle for 30 us apiece.
+constexpr int kGroup = 12;
+struct IgemmGroup { IgemmArgs g[kGroup]; };
+static_assert(sizeof(IgemmGroup) <= 4000, "kernel-argument segment is 4 KiB");
 
 template <typename T> struct Mfma;
 template <> struct Mfma<bf16_t> {
@@ -253,7 +260,9 @@ template <int KC> __device__ __forceinline__ int swz(int row, int c) {
 // coefficients derived in the prologue from the producer's statistics -- the consumer conv absorbs the producer's
 // normalise pass (one launch and one read+write of the tensor less per fused pair).
 template <typename T, int BM, int BN, int WM, int WN, int KC, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmGroup grp) {
+  const IgemmArgs& a = grp.g[blockIdx.y];
+  if ((int)blockIdx.x >= a.nbm * a.nbn) return;
   constexpr bool FAST = MODE >= 1, XF = MODE == 2;
   constexpr int NT = 64 * WM * WN;
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -469,9 +478,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KC, int MODE>
-int launch_(IgemmArgs& a, hipStream_t st) {
-  a.nbm = (a.M + BM - 1) / BM;
-  a.nbn = (a.N + BN - 1) / BN;
+int launch_(IgemmArgs* arr, int n, hipStream_t st) {
+  IgemmArgs& a = arr[0];
+  IgemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  for (int i = 0; i < n; ++i) {
+    arr[i].nbm = (arr[i].M + BM - 1) / BM;
+    arr[i].nbn = (arr[i].N + BN - 1) / BN;
+    grp.g[i] = arr[i];
+  }
   constexpr int kloop = 2 * (BM + BN) * KC * 16, stage = 64 * (BN + 4) * 4 + 2 * BN * WM * 4;   // staging rows + statistics partials
   const int lds = (kloop > stage ? kloop : stage) + (MODE == 2 ? 2 * a.Cin * (int)sizeof(float) : 0);
   constexpr int variant = (sizeof(T) == 2 ? 0 : 4) + (BN == 64 ? 1 : (BM == 64 ? 2 : (BM == 256 ? 3 : 0)));
@@ -479,7 +494,7 @@ int launch_(IgemmArgs& a, hipStream_t st) {
   if (g_prof_on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof.size() < kProfMax && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
-      rec.variant = variant; rec.flops = a.flops; prof = true;
+      rec.variant = variant; rec.flops = a.flops * n; prof = true;
       (void)hipEventRecord(rec.e0, st);
     }
   }
@@ -489,7 +504,7 @@ int launch_(IgemmArgs& a, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = lds;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, MODE>), dim3(a.nbm * a.nbn), dim3(64 * WM * WN), lds, st, a);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, MODE>), dim3(a.nbm * a.nbn, n), dim3(64 * WM * WN), lds, st, grp);
   if (prof) {
     (void)hipEventRecord(rec.e1, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -500,14 +515,15 @@ int launch_(IgemmArgs& a, hipStream_t st) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KC>
-int launch(IgemmArgs& a, hipStream_t st) {
+int launch(IgemmArgs* arr, int n, hipStream_t st) {
+  IgemmArgs& a = arr[0];
   constexpr int BK = KC * (16 / (int)sizeof(T));
   const bool fast = (a.Cin % BK == 0) && a.KH * a.KW <= 64;
   if (a.in_stats) {
     ST_CHECK(fast, "st_conv: the input transform needs Cin to be a multiple of %d", BK);
-    return launch_<T, BM, BN, WM, WN, KC, 2>(a, st);
+    return launch_<T, BM, BN, WM, WN, KC, 2>(arr, n, st);
   }
-  return fast ? launch_<T, BM, BN, WM, WN, KC, 1>(a, st) : launch_<T, BM, BN, WM, WN, KC, 0>(a, st);
+  return fast ? launch_<T, BM, BN, WM, WN, KC, 1>(arr, n, st) : launch_<T, BM, BN, WM, WN, KC, 0>(arr, n, st);
 }
 
 int g_tune[3] = {-1, -1, -1};   // (unused), kc, w8 (-1: take the environment default)
@@ -520,30 +536,32 @@ int tuning_w8() { if (g_tune[2] < 0) { const char* e = getenv("ST_IGEMM_W8"); g_
 int tuning_kc() { return tuning_get(1, "ST_IGEMM_KC"); }
 
 template <typename T, int KC>
-int dispatch_kc(IgemmArgs& a, hipStream_t st) {
+int dispatch_kc(IgemmArgs* arr, int n, hipStream_t st) {
+  IgemmArgs& a = arr[0];
   // Tile choice: fill >= ~1.5 waves of the 256 CUs where the problem allows it.
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (a.N <= 64) return launch<T, 128, 64, 4, 1, KC>(a, st);
-  if (tuning_w8() == 2 && a.M >= 256 * 64) return launch<T, 256, 128, 4, 2, KC>(a, st);
-  if (t128 >= 384) return tuning_w8() ? launch<T, 128, 128, 2, 4, KC>(a, st) : launch<T, 128, 128, 2, 2, KC>(a, st);
+  if (a.N <= 64) return launch<T, 128, 64, 4, 1, KC>(arr, n, st);
+  if (tuning_w8() == 2 && a.M >= 256 * 64) return launch<T, 256, 128, 4, 2, KC>(arr, n, st);
+  if (t128 >= 384) return tuning_w8() ? launch<T, 128, 128, 2, 4, KC>(arr, n, st) : launch<T, 128, 128, 2, 2, KC>(arr, n, st);
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
-  if (t64 >= 256 || a.M <= 64) return launch<T, 64, 128, 1, 4, KC>(a, st);
-  return tuning_w8() ? launch<T, 128, 128, 2, 4, KC>(a, st) : launch<T, 128, 128, 2, 2, KC>(a, st);
+  if (t64 >= 256 || a.M <= 64) return launch<T, 64, 128, 1, 4, KC>(arr, n, st);
+  return tuning_w8() ? launch<T, 128, 128, 2, 4, KC>(arr, n, st) : launch<T, 128, 128, 2, 2, KC>(arr, n, st);
 }
 
 template <typename T>
-int dispatch(IgemmArgs& a, hipStream_t st) {
+int dispatch(IgemmArgs* arr, int n, hipStream_t st) {
+  IgemmArgs& a = arr[0];
   // 64-byte tile rows halve the LDS footprint (3-4 blocks per CU instead of 2): the short-K pointwise layers
   // (K <= 256: 4 K steps or fewer, prologue/epilogue-bound) gain 8-15 % from the extra overlap, long-K layers lose.
   const int kc = tuning_kc();
   const bool short_k = a.KH * a.KW == 1 && a.K <= 256 && a.K % 64 == 0 && a.M >= 4096;
-  if ((kc == 4 || (kc == 0 && short_k)) && !a.korder) return dispatch_kc<T, 4>(a, st);
-  return dispatch_kc<T, 8>(a, st);
+  if ((kc == 4 || (kc == 0 && short_k)) && !a.korder) return dispatch_kc<T, 4>(arr, n, st);
+  return dispatch_kc<T, 8>(arr, n, st);
 }
 
 }  // namespace
 
-extern "C" int st_conv(const st_conv_desc* d, void* stream) {
+static int fill_args(const st_conv_desc* d, IgemmArgs& a) {
   ST_CHECK(d && d->x && d->w && d->y, "st_conv: null pointer");
   ST_CHECK(d->dtype == ST_F32 || d->dtype == ST_BF16, "st_conv: bad dtype %d", d->dtype);
   const int epc = d->dtype == ST_BF16 ? 8 : 4;
@@ -561,7 +579,6 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   ST_CHECK((long)d->B * d->Hin * d->Win * d->ldx < (1L << 40), "st_conv: input too large");
   ST_CHECK((d->scale == nullptr) == (d->shift == nullptr), "st_conv: scale and shift must be given together");
   ST_CHECK(!d->k_order || (d->Cin % (8 * epc) == 0 && d->KH * d->KW <= 64), "st_conv: k_order=1 needs Cin to be a multiple of %d", 8 * epc);
-  IgemmArgs a;
   a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.scale = d->scale; a.shift = d->shift;
   a.residual = d->residual; a.stats = d->stats;
   a.M = d->B * d->Ho * d->Wo; a.N = d->N; a.K = d->KH * d->KW * d->Cin;
@@ -573,9 +590,33 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_inv_count = d->in_count;   /* the kernel forms 1/count itself, as bn_act does */ a.in_eps = d->in_eps;
   ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f && d->ldx >= d->Cin && d->Cin <= 8192), "st_conv: input transform needs gamma, beta, count");
   a.flops = 2.0 * a.M * a.N * d->KH * d->KW * (d->Cin_logical > 0 ? d->Cin_logical : d->Cin);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  return d->dtype == ST_BF16 ? dispatch<bf16_t>(a, st) : dispatch<float>(a, st);
+  return 0;
 }
+
+extern "C" int st_conv(const st_conv_desc* d, void* stream) {
+  IgemmArgs a;
+  if (fill_args(d, a)) return 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return d->dtype == ST_BF16 ? dispatch<bf16_t>(&a, 1, st) : dispatch<float>(&a, 1, st);
+}
+
+// n (<= 12) independent problems of IDENTICAL shape, dtype and options in one launch (pointers differ)
+extern "C" int st_conv_batch(const st_conv_desc* d, int n, void* stream) {
+  ST_CHECK(d && n >= 1 && n <= kGroup, "st_conv_batch: 1..%d problems per launch", kGroup);
+  IgemmArgs arr[kGroup];
+  for (int i = 0; i < n; ++i) {
+    if (fill_args(d + i, arr[i])) return 1;
+    const st_conv_desc &p = d[0], &q = d[i];
+    ST_CHECK(p.dtype == q.dtype && p.out_dtype == q.out_dtype && p.B == q.B && p.Hin == q.Hin && p.Win == q.Win && p.Cin == q.Cin &&
+             p.Ho == q.Ho && p.Wo == q.Wo && p.N == q.N && p.KH == q.KH && p.KW == q.KW && p.stride == q.stride && p.pad == q.pad &&
+             p.ldx == q.ldx && p.ldw == q.ldw && p.ldy == q.ldy && p.k_order == q.k_order && (p.in_stats == nullptr) == (q.in_stats == nullptr),
+             "st_conv_batch: problem %d differs in shape or options from problem 0", i);
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return d->dtype == ST_BF16 ? dispatch<bf16_t>(arr, n, st) : dispatch<float>(arr, n, st);
+}
+
+
 
 // Benchmarking knob (tools/bench_conv.py): main-loop variant selection; -1 keeps the current value.
 extern "C" int st_tune(int ring, int kc, int w8) {

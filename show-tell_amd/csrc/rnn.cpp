@@ -30,7 +30,7 @@ inline int up8(int v) { return (v + 7) & ~7; }
 struct Plan {
   int G, GH, Np, Vp, maxw;
   size_t es;
-  size_t x0, y, gates, cst, dyl, dx0, dgx, dgh, dhc, dcc, hprev, tA, tB, wT, wThh, wTih, total;
+  size_t x0, y, gates, cst, dyl, dx0, dgx, dgh, dhc, dcc, hprev, tA, tB, wT, wThh, wTih, gA, gB, total;
 };
 
 Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
@@ -63,6 +63,10 @@ Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
   q.wT = take((w1 > w2 ? w1 : w2) * q.es);
   q.wThh = take(L * H * q.GH * q.es);               // W_hh^T and W_ih^T of every layer: the backward wavefront needs them all
   q.wTih = take(L * (size_t)q.maxw * q.GH * q.es);
+  // K-major operands of the 2L weight-gradient GEMMs (dgx^T, x^T, dgh^T, hprev^T of every layer), alive together so that
+  // the GEMMs can go out as one grouped launch
+  q.gA = take(2 * L * (size_t)q.GH * q.Np * q.es);
+  q.gB = take(2 * L * (size_t)q.maxw * q.Np * q.es);
   q.total = o;
   return q;
 }
@@ -253,22 +257,40 @@ extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, co
     if (rnn_bwd_gates_launch_batch(gc, ng, H, p->cell, dt, st)) return 1;
     if (rnn_gemm_launch_batch(mc, nm, dt, 0, 0, st)) return 1;
   }
-  // parameter gradients, one layer at a time over all its tokens
+  // parameter gradients: K-major copies of every layer's operands (the transposes also sum the bias gradients), then the
+  // 2L weight-gradient GEMMs -- 48 tiles each -- as grouped launches (st_conv_batch) that fill the chip
+  st_conv_desc gd[2 * ST_MAX_LAYERS];
+  int ng = 0;
+  auto wgrad = [&](const void* aT, const void* bT, float* dw, int rows, int cols) {   // dw[rows][cols] += aT[rows][Np] . bT[cols][Np]^T
+    st_conv_desc& d = gd[ng++];
+    memset(&d, 0, sizeof(d));
+    d.x = aT; d.w = bT; d.y = dw; d.dtype = dt; d.out_dtype = ST_F32;
+    d.B = rows; d.Hin = 1; d.Win = 1; d.Cin = Np; d.Ho = 1; d.Wo = 1; d.N = cols; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+    d.ldx = Np; d.ldw = Np; d.ldy = cols; d.accumulate = 1;
+  };
   for (int l = L - 1; l >= 0; --l) {
     const int in = l == 0 ? p->in0 : H;
     const char* xl = l == 0 ? reinterpret_cast<const char*>(x0) : ws + q.y + (size_t)(l - 1) * n * H * es;
     char* yl = ws + q.y + (size_t)l * n * H * es;
     char* dgx = dgxl(l);
     char* dgh = dghl(l);
-    // bias gradients ride on the K-major copies (column sums of the tile already in LDS)
+    char* aIh = ws + q.gA + (size_t)(2 * l) * GH * Np * es;
+    char* aHh = ws + q.gA + (size_t)(2 * l + 1) * GH * Np * es;
+    char* bIh = ws + q.gB + (size_t)(2 * l) * q.maxw * Np * es;
+    char* bHh = ws + q.gB + (size_t)(2 * l + 1) * q.maxw * Np * es;
     if (!gru && colsum_launch(dgh, g->b_hh[l], n, GH, GH, dt, st)) return 1;   // LSTM: dgh == dgx, transposed once
-    if (st_transpose_colsum(dgx, ws + q.tA, g->b_ih[l], dt, n, GH, GH, Np, stream)) return 1;
-    if (st_transpose(xl, ws + q.tB, dt, n, in, in, Np, stream)) return 1;
-    if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_ih[l], in, GH, in, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
+    if (st_transpose_colsum(dgx, aIh, g->b_ih[l], dt, n, GH, GH, Np, stream)) return 1;
+    if (st_transpose(xl, bIh, dt, n, in, in, Np, stream)) return 1;
     if (gather_hprev_launch(yl, s->rows_t, s->prev_row, ws + q.hprev, n, H, dt, st)) return 1;
-    if (gru && st_transpose_colsum(dgh, ws + q.tA, g->b_hh[l], dt, n, GH, GH, Np, stream)) return 1;
-    if (st_transpose(ws + q.hprev, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
-    if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_hh[l], H, GH, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
+    if (gru && st_transpose_colsum(dgh, aHh, g->b_hh[l], dt, n, GH, GH, Np, stream)) return 1;
+    if (st_transpose(ws + q.hprev, bHh, dt, n, H, H, Np, stream)) return 1;
+    if (in == H) {                       // same shape as the recurrent one: both join the group
+      wgrad(aIh, bIh, g->w_ih[l], GH, in);
+    } else if (gemm_nt(aIh, Np, bIh, Np, g->w_ih[l], in, GH, in, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
+    wgrad(gru ? aHh : aIh, bHh, g->w_hh[l], GH, H);
+  }
+  for (int i = 0; i < ng; i += 12) {
+    if (st_conv_batch(gd + i, ng - i < 12 ? ng - i : 12, stream)) return 1;
   }
   if (need_dx0 && !x0_override) {
     ST_CHECK(g->emb, "st_rnn_backward: embedding gradient buffer missing");

@@ -100,6 +100,20 @@ def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=N
     return out
 
 
+def gemm_nt_batch(As, Ws, outs, accumulate=False):
+    """Several y_i[M,N] (+)= a_i[M,K] @ w_i[N,K]^T of identical shape as ONE launch (st_conv_batch)."""
+    n = len(As)
+    arr = (ConvDesc * n)()
+    for i, (a, w, o) in enumerate(zip(As, Ws, outs)):
+        _dev(a, w, o)
+        M, K = a.shape
+        N = w.shape[0]
+        arr[i] = ConvDesc(_p(a), _p(w), _p(o), None, None, None, None, None, dt_code(a), _DT[o.dtype], M, 1, 1, K, 1, 1, N, 1, 1, 1, 0,
+                          a.stride(0), w.stride(0), o.stride(0), 0, int(accumulate), 0, 0, 0)
+    check(lib().st_conv_batch(arr, n, _stream()), "st_conv_batch")
+    return outs
+
+
 def bn_act(x, gamma, beta, stats=None, running=None, count=1.0, eps=1e-5, relu=True, res=None,
            res_bn=None, out=None, stats_replicas=0):
     """x: (..., C) channels-last.  res_bn = dict(gamma, beta, stats | running=(mean,var)) or None."""

@@ -270,6 +270,26 @@ def test_conv_input_bn_relu_equals_separate_pass(dtype, case):
     _close(y_fused, ref, dtype, "conv(relu(bn(x)))")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grouped_gemm_equals_single_launches(dtype):
+    """st_conv_batch: problems of identical shape in one launch (blockIdx.y = member) give exactly what st_conv gives
+    one by one (the decoder's per-layer weight-gradient GEMMs), including accumulation into the fp32 output."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    M, N, K, n = 1536, 512, 1864, 5
+    As = [torch.randn(M, K, generator=g).to("cuda", dtype) for _ in range(n)]
+    Ws = [(torch.randn(N, K, generator=g) / np.sqrt(K)).to("cuda", dtype) for _ in range(n)]
+    base = [torch.randn(M, N, generator=g).cuda() for _ in range(n)]
+    one = [ops.gemm_nt(a, w, out_dtype=torch.float32, out=b.clone(), accumulate=True) for a, w, b in zip(As, Ws, base)]
+    grp = ops.gemm_nt_batch(As, Ws, [b.clone() for b in base], accumulate=True)
+    torch.cuda.synchronize()
+    for o, q, a, w, b in zip(one, grp, As, Ws, base):
+        assert torch.equal(o, q)
+        _close(q, b.cpu() + a.float().cpu() @ w.float().cpu().t(), dtype, "grouped gemm")
+    with pytest.raises(Exception):
+        ops.gemm_nt_batch(As[:2], [Ws[0], Ws[1][:256].contiguous()], [base[0].clone(), base[1][:, :256].contiguous()])
+
+
 def test_bn_update_running_matches_torch():
     ops = _ops()
     g = torch.Generator().manual_seed(9)
