@@ -141,6 +141,11 @@ int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx,
 /* the same, and colsum[c] += sum_r x[r][c] (fp32 atomics) from the tile already in LDS: the bias gradient that goes with
  * every K-major copy of a gradient matrix in the decoder backward (autograd of nn.Linear / nn.GRU, main.py:151) */
 int st_transpose_colsum(const void* x, void* y, float* colsum, int dtype, int rows, int cols, int ldx, int ldy, void* stream);
+/* n <= 12 matrices of identical shape in one launch (the same operand of every decoder layer); colsum may be NULL or hold
+ * NULL entries.  With rows_t / prev_row (packed-sequence tables, st_packed_seq) output row r is read from source row
+ * prev_row[r], zero where rows_t[r] == 0: h_{t-1} of every token transposed straight out of the layer output. */
+int st_transpose_batch(const void* const* x, void* const* y, float* const* colsum, int n, int dtype, int rows, int cols,
+                       int ldx, int ldy, const int* rows_t, const int* prev_row, void* stream);
 /* conv weight repack: [Cout][Cin][KH][KW] fp32 (torch layout) -> [Cout][KH][KW][Cpad] dtype (k_order 0)
  * or [Cout][Cpad/CH][KH][KW][CH] with CH = 64 (bf16) / 32 (f32) channels (k_order 1, see st_conv_desc) */
 int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cpad, int k_order, void* stream);

@@ -81,6 +81,7 @@ _SIGS = {
     "st_cast": ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
     "st_transpose": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_transpose_colsum": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_transpose_batch": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p], c_i),
     "st_pack_conv_weight": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_cast2d": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_rnn_workspace_bytes": ([C.POINTER(RnnParams), C.POINTER(PackedSeq)], C.c_size_t),

@@ -350,23 +350,34 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const TI* __restrict__ x, T
 // y[c][r] = x[r][c] over 64x64 tiles, 16-byte global accesses on both sides (rows >= `rows` read as zero, so the pad
 // columns of y up to ldy are zero-filled); optionally colsum[c] += sum_r x[r][c] from the same tile -- the bias
 // gradient that always accompanies the K-major copy of a gradient matrix in the decoder backward.
+// blockIdx.z selects one of up to 12 matrices of identical shape (one launch for the same operand of every decoder
+// layer); with rows_t / prev_row the source row of output row r is prev_row[r] (zero when rows_t[r] == 0): the
+// "previous hidden state" matrix of BPTT is transposed straight out of the layer output, never materialised.
+struct TransposeBatch { const void* x[12]; void* y[12]; float* colsum[12]; };
+
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ colsum,
-                                                         int rows, int cols, int ldx, int ldy) {
+__global__ __launch_bounds__(256) void transpose_kernel(TransposeBatch tb, int rows, int cols, int ldx, int ldy,
+                                                         const int* __restrict__ rows_t, const int* __restrict__ prev_row) {
   constexpr int N = Vec<T>::N, CPR = 64 / N;       // elements per 16 bytes, chunks per 64-element tile row
   constexpr int LD = 64 + (sizeof(T) == 2 ? 2 : 1);
   __shared__ T tile[64][LD];
+  const T* __restrict__ x = reinterpret_cast<const T*>(tb.x[blockIdx.z]);
+  T* __restrict__ y = reinterpret_cast<T*>(tb.y[blockIdx.z]);
+  float* __restrict__ colsum = tb.colsum[blockIdx.z];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const bool vec_in = (ldx % N == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
     const int rl = i / CPR, cl = (i % CPR) * N;
     const int r = r0 + rl, c = c0 + cl;
+    long sr = r;                                     // source row
+    bool rok = r < rows;
+    if (rows_t && rok) { rok = rows_t[r] > 0; sr = rok ? prev_row[r] : 0; }
     float v[N];
-    if (r < rows && c + N <= cols && vec_in) {
-      Vec<T>::load(x + (long)r * ldx + c, v);
+    if (rok && c + N <= cols && vec_in) {
+      Vec<T>::load(x + sr * ldx + c, v);
     } else {
 #pragma unroll
-      for (int k = 0; k < N; ++k) v[k] = (r < rows && c + k < cols) ? to_f32<T>(x[(long)r * ldx + c + k]) : 0.f;
+      for (int k = 0; k < N; ++k) v[k] = (rok && c + k < cols) ? to_f32<T>(x[sr * ldx + c + k]) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) tile[rl][cl + k] = from_f32<T>(v[k]);
@@ -585,16 +596,28 @@ extern "C" int st_cast2d(const void* x, void* y, int from_dtype, int to_dtype, i
   return 0;
 }
 
-extern "C" int st_transpose_colsum(const void* x, void* y, float* colsum, int dtype, int rows, int cols, int ldx, int ldy, void* stream) {
-  ST_CHECK(x && y, "st_transpose: null pointer");
+extern "C" int st_transpose_batch(const void* const* x, void* const* y, float* const* colsum, int n, int dtype, int rows, int cols,
+                                  int ldx, int ldy, const int* rows_t, const int* prev_row, void* stream) {
+  ST_CHECK(x && y && n >= 1 && n <= 12, "st_transpose_batch: 1..12 matrices per launch");
   ST_DT_CHECK(dtype, "st_transpose");
   ST_CHECK(ldx >= cols && ldy >= rows, "st_transpose: leading dimensions too small (rows=%d cols=%d ldx=%d ldy=%d)", rows, cols, ldx, ldy);
-  const dim3 grid((cols + 63) / 64, (ldy + 63) / 64);
+  ST_CHECK((rows_t == nullptr) == (prev_row == nullptr), "st_transpose_batch: rows_t and prev_row go together");
+  TransposeBatch tb;
+  memset(&tb, 0, sizeof(tb));
+  for (int i = 0; i < n; ++i) {
+    ST_CHECK(x[i] && y[i], "st_transpose: null pointer");
+    tb.x[i] = x[i]; tb.y[i] = y[i]; tb.colsum[i] = colsum ? colsum[i] : nullptr;
+  }
+  const dim3 grid((cols + 63) / 64, (ldy + 63) / 64, n);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ST_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, colsum, rows, cols, ldx, ldy);
-  else hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, colsum, rows, cols, ldx, ldy);
+  if (dtype == ST_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, tb, rows, cols, ldx, ldy, rows_t, prev_row);
+  else hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, st, tb, rows, cols, ldx, ldy, rows_t, prev_row);
   ST_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int st_transpose_colsum(const void* x, void* y, float* colsum, int dtype, int rows, int cols, int ldx, int ldy, void* stream) {
+  return st_transpose_batch(&x, &y, &colsum, 1, dtype, rows, cols, ldx, ldy, nullptr, nullptr, stream);
 }
 
 extern "C" int st_transpose(const void* x, void* y, int dtype, int rows, int cols, int ldx, int ldy, void* stream) {

@@ -268,26 +268,37 @@ extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, co
     d.B = rows; d.Hin = 1; d.Win = 1; d.Cin = Np; d.Ho = 1; d.Wo = 1; d.N = cols; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
     d.ldx = Np; d.ldw = Np; d.ldy = cols; d.accumulate = 1;
   };
-  for (int l = L - 1; l >= 0; --l) {
+  const void* tx[4][ST_MAX_LAYERS]; void* ty[4][ST_MAX_LAYERS]; float* tc[4][ST_MAX_LAYERS];   // dgx, x, dgh, y(->hprev) of every layer
+  int nx = 0;                                                                                   // layers whose input width is H
+  for (int l = 0; l < L; ++l) {
     const int in = l == 0 ? p->in0 : H;
     const char* xl = l == 0 ? reinterpret_cast<const char*>(x0) : ws + q.y + (size_t)(l - 1) * n * H * es;
-    char* yl = ws + q.y + (size_t)l * n * H * es;
-    char* dgx = dgxl(l);
-    char* dgh = dghl(l);
     char* aIh = ws + q.gA + (size_t)(2 * l) * GH * Np * es;
     char* aHh = ws + q.gA + (size_t)(2 * l + 1) * GH * Np * es;
     char* bIh = ws + q.gB + (size_t)(2 * l) * q.maxw * Np * es;
     char* bHh = ws + q.gB + (size_t)(2 * l + 1) * q.maxw * Np * es;
-    if (!gru && colsum_launch(dgh, g->b_hh[l], n, GH, GH, dt, st)) return 1;   // LSTM: dgh == dgx, transposed once
-    if (st_transpose_colsum(dgx, aIh, g->b_ih[l], dt, n, GH, GH, Np, stream)) return 1;
-    if (st_transpose(xl, bIh, dt, n, in, in, Np, stream)) return 1;
-    if (gather_hprev_launch(yl, s->rows_t, s->prev_row, ws + q.hprev, n, H, dt, st)) return 1;
-    if (gru && st_transpose_colsum(dgh, aHh, g->b_hh[l], dt, n, GH, GH, Np, stream)) return 1;
-    if (st_transpose(ws + q.hprev, bHh, dt, n, H, H, Np, stream)) return 1;
-    if (in == H) {                       // same shape as the recurrent one: both join the group
+    tx[0][l] = dgxl(l); ty[0][l] = aIh; tc[0][l] = g->b_ih[l];
+    tx[2][l] = dghl(l); ty[2][l] = aHh; tc[2][l] = g->b_hh[l];
+    tx[3][l] = ws + q.y + (size_t)l * n * H * es; ty[3][l] = bHh; tc[3][l] = nullptr;
+    if (in == H) {                       // same shape as the recurrent one: joins the groups
+      tx[1][nx] = xl; ty[1][nx] = bIh; tc[1][nx] = nullptr; ++nx;
       wgrad(aIh, bIh, g->w_ih[l], GH, in);
-    } else if (gemm_nt(aIh, Np, bIh, Np, g->w_ih[l], in, GH, in, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
+    } else {
+      if (st_transpose(xl, bIh, dt, n, in, in, Np, stream)) return 1;
+    }
     wgrad(gru ? aHh : aIh, bHh, g->w_hh[l], GH, H);
+    if (!gru && colsum_launch(dghl(l), g->b_hh[l], n, GH, GH, dt, st)) return 1;   // LSTM: dgh == dgx, transposed once
+  }
+  // one launch per operand kind over all layers; the bias gradients ride on the gate-gradient transposes and h_{t-1}
+  // is gathered by the transpose itself (packed-sequence prev_row table)
+  if (st_transpose_batch(tx[0], ty[0], tc[0], L, dt, n, GH, GH, Np, nullptr, nullptr, stream)) return 1;
+  if (nx && st_transpose_batch(tx[1], ty[1], nullptr, nx, dt, n, H, H, Np, nullptr, nullptr, stream)) return 1;
+  if (gru && st_transpose_batch(tx[2], ty[2], tc[2], L, dt, n, GH, GH, Np, nullptr, nullptr, stream)) return 1;
+  if (st_transpose_batch(tx[3], ty[3], nullptr, L, dt, n, H, H, Np, s->rows_t, s->prev_row, stream)) return 1;
+  for (int l = 0; l < L; ++l) {          // layers with a different input width: their dW_ih on its own
+    const int in = l == 0 ? p->in0 : H;
+    if (in != H && gemm_nt(ws + q.gA + (size_t)(2 * l) * GH * Np * es, Np, ws + q.gB + (size_t)(2 * l) * q.maxw * Np * es, Np,
+                           g->w_ih[l], in, GH, in, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
   }
   for (int i = 0; i < ng; i += 12) {
     if (st_conv_batch(gd + i, ng - i < 12 ? ng - i : 12, stream)) return 1;
