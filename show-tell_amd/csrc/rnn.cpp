@@ -215,11 +215,18 @@ extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, co
   auto wTih = [&](int l) { return ws + q.wTih + (size_t)l * q.maxw * GH * es; };
   if (hipMemsetAsync(ws + q.dhc, 0, (size_t)L * s->B * H * sizeof(float), st) != hipSuccess ||
       hipMemsetAsync(ws + q.dcc, 0, (size_t)L * s->B * H * sizeof(float), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
-  for (int l = 0; l < L; ++l) {
-    const int in = l == 0 ? p->in0 : H;
-    // K-major operands of dh_{t-1} += dgh_t W_hh  and  dx_t = dgx_t W_ih
-    if (st_transpose(p->w_hh[l], wThh(l), dt, GH, H, H, GH, stream)) return 1;
-    if ((l > 0 || need_dx0) && st_transpose(p->w_ih[l], wTih(l), dt, GH, in, in, GH, stream)) return 1;
+  {   // K-major operands of dh_{t-1} += dgh_t W_hh  and  dx_t = dgx_t W_ih: one batched transpose per kind
+    const void* wx[2][ST_MAX_LAYERS]; void* wy[2][ST_MAX_LAYERS];
+    int ni = 0;
+    for (int l = 0; l < L; ++l) {
+      const int in = l == 0 ? p->in0 : H;
+      wx[0][l] = p->w_hh[l]; wy[0][l] = wThh(l);
+      if (!(l > 0 || need_dx0)) continue;
+      if (in == H) { wx[1][ni] = p->w_ih[l]; wy[1][ni] = wTih(l); ++ni; }
+      else if (st_transpose(p->w_ih[l], wTih(l), dt, GH, in, in, GH, stream)) return 1;
+    }
+    if (st_transpose_batch(wx[0], wy[0], nullptr, L, dt, GH, H, H, GH, nullptr, nullptr, stream)) return 1;
+    if (ni && st_transpose_batch(wx[1], wy[1], nullptr, ni, dt, GH, H, H, GH, nullptr, nullptr, stream)) return 1;
   }
   // reversed wavefront: the cells of a diagonal need only cells of the diagonal above
   for (int d = T + L - 2; d >= 0; --d) {
