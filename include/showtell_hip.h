@@ -72,6 +72,8 @@ typedef struct {
    * A operand becomes relu(batchnorm(x)) with batch statistics in_stats = [sum | sumsq] over in_count rows -- the
    * producer's normalise pass is absorbed by this conv.  Needs Cin % 64 == 0 (bf16) / 32 (f32).  NULL = off. */
   const float* in_stats; const float* in_gamma; const float* in_beta; float in_count, in_eps;
+  int split_k;          /* > 1 (plain GEMM, fp32 output, K % (split_k*64|32) == 0): K is cut into split_k slices that run as
+                         * one grouped launch and add their tiles with fp32 atomics -- for products with few output tiles */
 } st_conv_desc;
 
 int st_conv(const st_conv_desc* d, void* stream);
@@ -219,6 +221,9 @@ typedef struct {
   const long* caption;                                          /* device int64 [B][Tcap] */
 } st_packed_seq;
 
+/* leading dimension (elements) for the logits / dlogits rows of a V-entry vocabulary: up8(V) below 2048 entries, else V
+ * rounded up to 512 (the backward product over K = V is then split into 8 even slices); pad columns are zero-filled */
+int st_rnn_vocab_ld(int V);
 size_t st_rnn_workspace_bytes(const st_rnn_params* p, const st_packed_seq* s);
 int st_rnn_forward(const st_rnn_params* p, const st_packed_seq* s, const void* x0_override, const void* feat,
                    void* workspace, size_t workspace_bytes, void* logits, int logits_dtype, int ldl,

@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
                 ("B", c_i), ("Hin", c_i), ("Win", c_i), ("Cin", c_i), ("Ho", c_i), ("Wo", c_i), ("N", c_i),
                 ("KH", c_i), ("KW", c_i), ("stride", c_i), ("pad", c_i),
                 ("ldx", c_i), ("ldw", c_i), ("ldy", c_i), ("relu", c_i), ("accumulate", c_i), ("Cin_logical", c_i), ("k_order", c_i), ("stats_replicas", c_i),
-                ("in_stats", c_p), ("in_gamma", c_p), ("in_beta", c_p), ("in_count", c_f), ("in_eps", c_f)]
+                ("in_stats", c_p), ("in_gamma", c_p), ("in_beta", c_p), ("in_count", c_f), ("in_eps", c_f), ("split_k", c_i)]
 
 
 class BnActDesc(C.Structure):
@@ -84,6 +84,7 @@ _SIGS = {
     "st_transpose_batch": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p], c_i),
     "st_pack_conv_weight": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_cast2d": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    "st_rnn_vocab_ld": ([c_i], c_i),
     "st_rnn_workspace_bytes": ([C.POINTER(RnnParams), C.POINTER(PackedSeq)], C.c_size_t),
     "st_rnn_forward": ([C.POINTER(RnnParams), C.POINTER(PackedSeq), c_p, c_p, c_p, C.c_size_t, c_p, c_i, c_i, c_p, c_i, c_p], c_i),
     "st_rnn_backward": ([C.POINTER(RnnParams), C.POINTER(RnnGrads), C.POINTER(PackedSeq), c_p, c_p, c_i, c_p, c_p, C.c_size_t,

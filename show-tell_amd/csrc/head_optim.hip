@@ -139,9 +139,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 int gemm_nt_(const void* a, int lda, const void* w, int ldw, void* y, int ldy, int M, int N, int K, int dtype, int out_dtype,
-             const float* bias, int accumulate, void* stream) {
+             const float* bias, int accumulate, void* stream, int split_k = 0) {
   st_conv_desc d;
   memset(&d, 0, sizeof(d));
+  d.split_k = split_k;
   d.x = a; d.w = w; d.y = y; d.bias = bias; d.dtype = dtype; d.out_dtype = out_dtype;
   d.B = M; d.Hin = 1; d.Win = 1; d.Cin = K; d.Ho = 1; d.Wo = 1; d.N = N; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
   d.ldx = lda; d.ldw = ldw; d.ldy = ldy; d.accumulate = accumulate;
@@ -168,7 +169,10 @@ extern "C" int st_linear_bn1d_forward(const void* x, const void* w, const float*
   ST_CHECK(B > 0 && F % 8 == 0 && E % 4 == 0, "st_linear_bn1d_forward: need F%%8==0 and E%%4==0 (F=%d E=%d)", F, E);
   ST_CHECK(!train || B > 1, "Expected more than 1 value per channel when training (BatchNorm1d, B=%d)", B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (gemm_nt_(x, F, w, F, z_out, E, B, E, F, dtype, ST_F32, bias, 0, stream)) return 1;
+  // B x E output tiles are few (4 at B = 128, E = 512) and K = F is long: 8 K slices in one grouped launch
+  const int bk = dtype == ST_BF16 ? 64 : 32;
+  const int split = (F % (8 * bk) == 0 && (long)B * E <= 256 * 128 * 64) ? 8 : 0;
+  if (gemm_nt_(x, F, w, F, z_out, E, B, E, F, dtype, ST_F32, bias, 0, stream, split)) return 1;
   const dim3 grid((E + kBnTX - 1) / kBnTX), block(kBnTX, kBnTY);
   if (dtype == ST_BF16)
     hipLaunchKernelGGL(bn1d_fwd_kernel<bf16_t>, grid, block, 0, st, z_out, gamma, beta, running_mean, running_var, save_mean, save_rstd,

@@ -48,6 +48,7 @@ struct IgemmArgs {
   int Hin, Win, Cin, Ho, Wo, KH, KW, stride, pad;
   int ldx, ldw, ldy;
   int relu, accumulate, out_f32, korder, srep;
+  int atomic;   // split-K member: fp32 output accumulated with atomics
   const float* in_stats; const float* in_gamma; const float* in_beta; float in_inv_count, in_eps;   // input BN+ReLU (XF)
   unsigned long long* stamps;   // debug: per-block phase timestamps (tools/conv_stamps.py), normally NULL
   int nbm, nbn;
@@ -182,6 +183,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         const int n = bn * BN + nl;
         if (n < a.N) atomicAdd(sdst + (t < BN ? n : a.N + n), v);
       }
+    }
+    if (a.atomic) {   // split-K slice: the slices of one output tile meet in memory; 64 consecutive floats per wave-instruction
+      if (storer) for (int idx = stid; idx < 64 * BN; idx += NT) {
+        const int r = idx / BN, c = idx - r * BN;
+        const int m = bm * BM + h * 64 + r, n = bn * BN + c;
+        if (m < a.M && n < a.N) atomicAdd(reinterpret_cast<float*>(a.y) + (long)m * a.ldy + n, stage[r * SROW + c]);
+      }
+      continue;
     }
     constexpr int CPR = BN / 8;                       // 8-channel chunks per row
     constexpr int RPI = NT / CPR;                     // rows per pass
@@ -586,7 +595,7 @@ static int fill_args(const st_conv_desc* d, IgemmArgs& a) {
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy;
   a.relu = d->relu; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == ST_F32;
-  a.korder = d->k_order; a.srep = d->stats_replicas; a.stamps = g_stamps;
+  a.korder = d->k_order; a.srep = d->stats_replicas; a.stamps = g_stamps; a.atomic = 0;
   a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_inv_count = d->in_count;   /* the kernel forms 1/count itself, as bn_act does */ a.in_eps = d->in_eps;
   ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f && d->ldx >= d->Cin && d->Cin <= 8192), "st_conv: input transform needs gamma, beta, count");
   a.flops = 2.0 * a.M * a.N * d->KH * d->KW * (d->Cin_logical > 0 ? d->Cin_logical : d->Cin);
@@ -597,6 +606,27 @@ extern "C" int st_conv(const st_conv_desc* d, void* stream) {
   IgemmArgs a;
   if (fill_args(d, a)) return 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->split_k > 1) {
+    // Split-K for plain GEMMs whose M x N gives too few tiles (dy = dlogits W_lin: 60 tiles, K = 10240): S members of one
+    // grouped launch take K/S each and add their fp32 tiles with atomics; bias goes with slice 0.
+    const int S = d->split_k, bk = d->dtype == ST_BF16 ? 64 : 32;
+    ST_CHECK(S <= kGroup && d->KH == 1 && d->KW == 1 && d->Hin == 1 && d->Win == 1 && d->out_dtype == ST_F32 && !d->relu && !d->scale &&
+             !d->residual && !d->stats && !d->in_stats && d->Cin % (S * bk) == 0,
+             "st_conv: split_k=%d needs a plain fp32-output GEMM with K a multiple of %d", S, S * bk);
+    if (!d->accumulate && hipMemsetAsync(d->y, 0, (size_t)a.M * d->ldy * sizeof(float), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
+    IgemmArgs arr[kGroup];
+    const int ks = d->Cin / S;
+    const size_t es = d->dtype == ST_BF16 ? 2 : 4;
+    for (int i = 0; i < S; ++i) {
+      arr[i] = a;
+      arr[i].x = reinterpret_cast<const char*>(a.x) + (size_t)i * ks * es;
+      arr[i].w = reinterpret_cast<const char*>(a.w) + (size_t)i * ks * es;
+      arr[i].K = ks; arr[i].Cin = ks; arr[i].atomic = 1; arr[i].accumulate = 0;
+      if (i) arr[i].bias = nullptr;
+      arr[i].flops = a.flops / S;
+    }
+    return d->dtype == ST_BF16 ? dispatch<bf16_t>(arr, S, st) : dispatch<float>(arr, S, st);
+  }
   return d->dtype == ST_BF16 ? dispatch<bf16_t>(&a, 1, st) : dispatch<float>(&a, 1, st);
 }
 

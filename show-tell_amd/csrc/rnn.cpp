@@ -38,7 +38,7 @@ Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
   q.G = p->cell == ST_CELL_GRU ? 3 : 4;
   q.GH = q.G * p->H;
   q.Np = up8(s->ntok);
-  q.Vp = up8(p->V);
+  q.Vp = st_rnn_vocab_ld(p->V);
   q.es = st_dtype_size(p->dtype);
   q.maxw = p->in0 > p->H ? p->in0 : p->H;
   const size_t n = s->ntok, L = p->L, H = p->H;
@@ -72,10 +72,11 @@ Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
 }
 
 int gemm_nt(const void* a, int lda, const void* w, int ldw, void* y, int ldy, int M, int N, int K, int dtype, int out_dtype,
-            const float* bias, int accumulate, void* stream) {
+            const float* bias, int accumulate, void* stream, int split_k = 0) {
   if (M <= 0 || N <= 0) return 0;
   st_conv_desc d;
   memset(&d, 0, sizeof(d));
+  d.split_k = split_k;
   d.x = a; d.w = w; d.y = y; d.bias = bias; d.dtype = dtype; d.out_dtype = out_dtype;
   d.B = M; d.Hin = 1; d.Win = 1; d.Cin = K; d.Ho = 1; d.Wo = 1; d.N = N; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
   d.ldx = lda; d.ldw = ldw; d.ldy = ldy; d.accumulate = accumulate;
@@ -104,6 +105,10 @@ int check_common(const st_rnn_params* p, const st_packed_seq* s, const char* who
 }
 
 }  // namespace
+
+// Leading dimension to give logits / dlogits rows: V rounded up to 8 elements for small vocabularies, to 512 (8 K tiles of
+// 64) from 2048 entries on, so that the K = V product of the backward pass can be split evenly.
+extern "C" int st_rnn_vocab_ld(int V) { return V < 2048 ? up8(V) : (V + 511) / 512 * 512; }
 
 extern "C" size_t st_rnn_workspace_bytes(const st_rnn_params* p, const st_packed_seq* s) {
   if (!p || !s) return 0;
@@ -188,13 +193,18 @@ extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, co
 
   if (dlogits) {
     ST_CHECK(p->w_lin && g->w_lin && g->b_lin, "st_rnn_backward: vocabulary projection gradients requested without buffers");
-    ST_CHECK(ldd >= q.Vp && ldd % 8 == 0, "st_rnn_backward: dlogits leading dimension %d must be a multiple of 8 and >= %d", ldd, q.Vp);
+    ST_CHECK(ldd >= up8(p->V) && ldd % 8 == 0 && ldd <= q.Vp, "st_rnn_backward: dlogits leading dimension %d must be a multiple of 8 in [%d, %d]",
+             ldd, up8(p->V), q.Vp);
     // db = colsum(dlogits);  dW_lin += dlogits^T y_top;  dy_top = dlogits W_lin
     if (st_transpose_colsum(dlogits, ws + q.tA, g->b_lin, dt, n, p->V, ldd, Np, stream)) return 1;
     if (st_transpose(ytop, ws + q.tB, dt, n, H, H, Np, stream)) return 1;
     if (gemm_nt(ws + q.tA, Np, ws + q.tB, Np, g->w_lin, H, p->V, H, Np, dt, ST_F32, nullptr, 1, stream)) return 1;
-    if (st_transpose(p->w_lin, ws + q.wT, dt, p->V, H, H, q.Vp, stream)) return 1;
-    if (gemm_nt(dlogits, ldd, ws + q.wT, q.Vp, dy, H, n, H, q.Vp, dt, ST_F32, nullptr, 0, stream)) return 1;
+    // dy = dlogits W_lin is 15 x 4 output tiles over K = V: with the padded leading dimension (st_rnn_vocab_ld: a multiple
+    // of 8 K tiles, pad columns zero on both sides) it runs as 8 K slices in one grouped launch
+    if (st_transpose(p->w_lin, ws + q.wT, dt, p->V, H, H, ldd, stream)) return 1;
+    const int bk = dt == ST_BF16 ? 64 : 32;
+    const int split = (ldd % (8 * bk) == 0 && ldd >= 16 * bk) ? 8 : 0;
+    if (gemm_nt(dlogits, ldd, ws + q.wT, ldd, dy, H, n, H, ldd, dt, ST_F32, nullptr, 0, stream, split)) return 1;
     if (dy_top_extra) { st_set_error("st_rnn_backward: dlogits and dy_top_extra are exclusive"); return 1; }
   } else {
     ST_CHECK(dy_top_extra, "st_rnn_backward: need dlogits or dy_top");

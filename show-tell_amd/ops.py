@@ -81,7 +81,7 @@ def stem_conv_s2d(images, w_packed, cpad, dtype, stats=None, scale=None, shift=N
 
 
 def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=None, relu=False,
-            lda=None, ldw=None, K=None):
+            lda=None, ldw=None, K=None, split_k=0):
     """y[M,N] = a[M,K] @ w[N,K]^T (+bias).  a, w may carry padded leading dimensions."""
     _dev(a, w, bias, out, stats)
     M = a.shape[0]
@@ -96,6 +96,7 @@ def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=N
     d = ConvDesc(_p(a), _p(w), _p(out), _p(bias), None, None, None, _p(stats),
                  dt_code(a), _DT[out.dtype], M, 1, 1, K, 1, 1, N, 1, 1, 1, 0,
                  lda, ldw, ldy, int(relu), int(accumulate), 0, 0)
+    d.split_k = int(split_k)
     check(lib().st_conv(C.byref(d), _stream()), "st_conv(gemm)")
     return out
 

@@ -78,7 +78,7 @@ class _DecoderFn(torch.autograd.Function):
         featd = featd if featd.dtype == dt else ops.cast(featd.float(), dt)
         nbytes = lib().st_rnn_workspace_bytes(C.byref(prm), C.byref(seq))
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        V, Vp, n = m.vocab_size, up8(m.vocab_size), plan.ntok
+        V, Vp, n = m.vocab_size, lib().st_rnn_vocab_ld(m.vocab_size), plan.ntok
         targets = torch.empty(n, device=dev, dtype=torch.long)
         logits = torch.empty(n, Vp, device=dev, dtype=torch.float32 if mode == "logits" else dt)
         check(lib().st_rnn_forward(C.byref(prm), C.byref(seq), None, _cp(featd), _cp(ws), nbytes, _cp(logits),
@@ -100,10 +100,10 @@ class _DecoderFn(torch.autograd.Function):
         dev = gout.device
         dt = m.compute_dtype
         dtc = ST_F32 if dt == torch.float32 else ST_BF16
-        V, Vp, n = m.vocab_size, up8(m.vocab_size), plan.ntok
+        V, Vp, n = m.vocab_size, lib().st_rnn_vocab_ld(m.vocab_size), plan.ntok
         if ctx.mode == "logits":
             g = gout if gout.dtype == torch.float32 else gout.float()
-            dlog = torch.empty(n, Vp, device=dev, dtype=dt)
+            dlog = torch.zeros(n, Vp, device=dev, dtype=dt)   # pad columns feed the backward GEMM as K: must be zero
             gs = g.stride(0) if g.stride(1) == 1 else None
             if gs is None:
                 g = g.contiguous(); gs = g.stride(0)

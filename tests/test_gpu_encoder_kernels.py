@@ -290,6 +290,24 @@ def test_grouped_gemm_equals_single_launches(dtype):
         ops.gemm_nt_batch(As[:2], [Ws[0], Ws[1][:256].contiguous()], [base[0].clone(), base[1][:, :256].contiguous()])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,S,acc", [(1857, 512, 10240, 8, False), (128, 512, 2048, 8, False), (77, 96, 1024, 4, True)])
+def test_split_k_gemm(dtype, M, N, K, S, acc):
+    """st_conv_desc.split_k: K slices of a plain GEMM in one grouped launch, fp32 tiles added with atomics (bias once)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).to("cuda", dtype)
+    w = (torch.randn(N, K, generator=g) / np.sqrt(K)).to("cuda", dtype)
+    bias = torch.randn(N, generator=g).cuda()
+    base = torch.randn(M, N, generator=g).cuda()
+    out = base.clone() if acc else torch.full((M, N), 9.0, device="cuda")
+    ops.gemm_nt(a, w, out_dtype=torch.float32, bias=bias, out=out, accumulate=acc, split_k=S)
+    ref = a.float().cpu() @ w.float().cpu().t() + bias.cpu() + (base.cpu() if acc else 0)
+    _close(out, ref, torch.float32 if dtype == torch.float32 else dtype, "split-K gemm")
+    one = ops.gemm_nt(a, w, out_dtype=torch.float32, bias=bias, out=base.clone() if acc else None, accumulate=acc)
+    assert (one - out).abs().max().item() <= 1e-3 * ref.abs().max().item()
+
+
 def test_bn_update_running_matches_torch():
     ops = _ops()
     g = torch.Generator().manual_seed(9)
