@@ -63,7 +63,9 @@ template <typename T, int NG, bool HAS_X, int MT>
 __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int mbase, int n0, int r16, int q4, int kslice,
                                            f32x4 (&accH)[MT][NG], f32x4 (&accX)[MT][NG]) {
   constexpr int EPC = Mfma<T>::EPC;
-  constexpr int UNR = 4;
+  // K steps requested per round trip; the fused two-operand, two-row-tile form halves it to stay within 2 waves per SIMD
+  // (260 -> ~170 VGPRs: two blocks per CU overlap instead of one)
+  constexpr int UNR = (HAS_X && MT == 2) ? 2 : 4;
   const int n = n0 + r16;
   const bool nok = n < a.N;
   // The kernel is latency bound (every fragment comes from L2), so bytes in flight per wave are the lever: K is split
