@@ -549,7 +549,10 @@ int dispatch_kc(IgemmArgs* arr, int n, hipStream_t st) {
   IgemmArgs& a = arr[0];
   // Tile choice: fill >= ~1.5 waves of the 256 CUs where the problem allows it.
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (a.N <= 64) return launch<T, 128, 64, 4, 1, KC>(arr, n, st);
+  if (a.N <= 64) {
+    if constexpr (KC == 8) { if (tuning_w8() && tuning_w8() != 3) return launch<T, 128, 64, 4, 2, KC>(arr, n, st); }   // 8 waves: the loader needs 64 rows per pass
+    return launch<T, 128, 64, 4, 1, KC>(arr, n, st);
+  }
   if (tuning_w8() == 2 && a.M >= 256 * 64) return launch<T, 256, 128, 4, 2, KC>(arr, n, st);
   if (t128 >= 384) return tuning_w8() ? launch<T, 128, 128, 2, 4, KC>(arr, n, st) : launch<T, 128, 128, 2, 2, KC>(arr, n, st);
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
