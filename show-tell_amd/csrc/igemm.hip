@@ -322,10 +322,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmGroup grp) {
       hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
       if (FAST) {
         arow[i] = X + ((long)(pixbase[i] + hi0 * a.Win + wi0) * a.ldx + ccol * EPC);
-        for (int fh = 0; fh < a.KH; ++fh)
-          for (int fw = 0; fw < a.KW; ++fw)
-            if ((unsigned)(hi0 + fh) < (unsigned)a.Hin && (unsigned)(wi0 + fw) < (unsigned)a.Win)
-              amask[i] |= 1ull << (fh * a.KW + fw);
+        // in-bounds taps form a rectangle [h0,h1) x [w0,w1): one row mask, shifted per filter row
+        const int h0 = hi0 < 0 ? -hi0 : 0, h1 = a.Hin - hi0 < a.KH ? a.Hin - hi0 : a.KH;
+        const int w0 = wi0 < 0 ? -wi0 : 0, w1 = a.Win - wi0 < a.KW ? a.Win - wi0 : a.KW;
+        if (h1 > h0 && w1 > w0) {
+          const unsigned long long wm = ((1ull << w1) - 1ull) & ~((1ull << w0) - 1ull);
+          for (int fh = h0; fh < h1; ++fh) amask[i] |= wm << (fh * a.KW);
+        }
       }
     }
   }
