@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE: 128)")
     ap.add_argument("--vocab", type=int, default=10000)
+    ap.add_argument("--no-pipeline", action="store_true", help="do not issue the next minibatch's frozen backbone ahead on a second stream")
     ap.add_argument("--optimizer", default="SGD", choices=["SGD", "Adam"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
@@ -109,14 +110,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        trainer.step(image, caption, lens)
+    # Steps are software-pipelined: the frozen backbone forward of minibatch k+1 is issued on a second stream while step k
+    # runs its trainable part (train.py).  Nothing is carried across the timing boundaries: the last warm-up step and the
+    # last timed step prefetch nothing, so the timed region holds exactly `steps` complete steps (the first one unpipelined).
+    pipe = not a.no_pipeline
+    for k in range(a.warmup):
+        trainer.step(image, caption, lens, next_image=image if (pipe and k + 1 < a.warmup) else None)
     trainer.flush()
     barrier()
     t0 = time.perf_counter()
     loss = None
-    for _ in range(a.steps):
-        loss = trainer.step(image, caption, lens)
+    for k in range(a.steps):
+        loss = trainer.step(image, caption, lens, next_image=image if (pipe and k + 1 < a.steps) else None)
     trainer.flush()
     barrier()
     dt = time.perf_counter() - t0

@@ -8,6 +8,12 @@ hides behind the frozen backbone:  the previous step's gradient all-reduce and o
 update are completed AFTER this step's backbone forward (which reads only frozen weights,
 cnn.py:47) and BEFORE its trainable part.  With one GPU the order is irrelevant and the result
 is identical to the reference loop; `flush()` applies the last pending update.
+
+Software pipelining across steps (`step(..., next_image=...)`): because the backbone is frozen, the forward of the NEXT
+minibatch depends on nothing this step computes.  When the caller hands the next images over (a data loader always has
+them), their backbone forward is issued on a second HIP stream at the start of this step and runs beside this step's
+head / decoder / backward, whose launch-bound wavefront and few-tile GEMMs leave most CUs idle.  The arithmetic and
+its order per sample are unchanged; only the schedule is.
 """
 import numpy as np
 import torch
@@ -38,6 +44,8 @@ class Trainer:
         self.cnn, self.rnn, self.opt = cnn, rnn, optimizer
         self.reducer = GradAllReducer(world_size)
         self.pending = False
+        self._pre = None      # (images, pooled features, event): backbone forward issued ahead on the side stream
+        self._side = None
 
     def trainable_params(cnn, rnn):
         """main.py:96: rnn.parameters() + cnn.linear_secondlast_layer + cnn.last_layer."""
@@ -50,9 +58,35 @@ class Trainer:
             self.opt.step()
             self.pending = False
 
-    def step(self, image, caption, caption_len):
+    def _backbone(self, image):
+        """Backbone features of `image` on the current stream; takes the result issued ahead by `_prefetch` if it is the same batch."""
+        main = torch.cuda.current_stream()
+        if self._pre is not None and self._pre[0] is image:
+            _, pooled, ev = self._pre
+            self._pre = None
+            main.wait_event(ev)
+            pooled.record_stream(main)
+            return pooled
+        if self._side is not None:
+            main.wait_stream(self._side)               # the engine workspace and the BN buffers are shared with the side stream
+        self._pre = None
+        return self.cnn.backbone_features(image)
+
+    def _prefetch(self, image):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())   # after everything already queued (previous backbone, BN buffers)
+        with torch.cuda.stream(self._side):
+            pooled = self.cnn.backbone_features(image)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._pre = (image, pooled, ev)
+
+    def step(self, image, caption, caption_len, next_image=None):
         cnn, rnn = self.cnn, self.rnn
-        pooled = cnn.backbone_features(image)          # frozen, detached (cnn.py:46-47): overlaps the all-reduce
+        pooled = self._backbone(image)                 # frozen, detached (cnn.py:46-47): overlaps the all-reduce
+        if next_image is not None:
+            self._prefetch(next_image)                 # next minibatch's frozen backbone, beside this step's trainable part
         self._apply_pending()                          # previous step's optimizer.step() (main.py:152)
         self.opt.zero_grad()                           # main.py:146
         feat = linear_bn1d(pooled, cnn.linear_secondlast_layer, cnn.last_layer, cnn.training, cnn.compute_dtype)
