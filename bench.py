@@ -110,18 +110,21 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # Steps are software-pipelined: the frozen backbone forward of minibatch k+1 is issued on a second stream while step k
-    # runs its trainable part (train.py).  Nothing is carried across the timing boundaries: the last warm-up step and the
-    # last timed step prefetch nothing, so the timed region holds exactly `steps` complete steps (the first one unpipelined).
+    # Steps are software-pipelined: the frozen backbone forwards of minibatches k+1 and k+2 are issued on two side streams
+    # while step k runs its trainable part (train.py).  Nothing is carried across the timing boundaries: the last warm-up
+    # steps and the last timed steps prefetch nothing beyond their loop, so the timed region holds exactly `steps` complete
+    # steps (the first one unpipelined, the second half-pipelined).
     pipe = not a.no_pipeline
+    def ahead(k, n):   # the minibatches after step k that exist inside this loop (never across a timing boundary)
+        return dict(next_image=image if (pipe and k + 1 < n) else None, next_next_image=image if (pipe and k + 2 < n) else None)
     for k in range(a.warmup):
-        trainer.step(image, caption, lens, next_image=image if (pipe and k + 1 < a.warmup) else None)
+        trainer.step(image, caption, lens, **ahead(k, a.warmup))
     trainer.flush()
     barrier()
     t0 = time.perf_counter()
     loss = None
     for k in range(a.steps):
-        loss = trainer.step(image, caption, lens, next_image=image if (pipe and k + 1 < a.steps) else None)
+        loss = trainer.step(image, caption, lens, **ahead(k, a.steps))
     trainer.flush()
     barrier()
     dt = time.perf_counter() - t0

@@ -163,6 +163,8 @@ int st_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin,
  * unknown version.  Outputs (each optional): feat_nhwc_out (B,h,w,F) dtype;
  * pooled_out (B,F) pooled_dtype (cnn.py:48); ncp_out (B,F,h*w) fp32 (cnn_attn.py:49).
  * train != 0: batch statistics + running-buffer update (main.py:125); else eval mode.
+ * train == 2: batch statistics, but the running buffers are left for st_resnet_update_running (same workspace) -- for
+ * forwards of successive minibatches that run concurrently on different streams and must apply their momentum updates in order.
  * ---------------------------------------------------------------------------------- */
 typedef struct st_resnet st_resnet;
 int st_resnet_create(int version, int dtype, st_resnet** out);
@@ -181,6 +183,9 @@ int st_resnet_forward(const st_resnet* r, const float* images_nchw, int B, int H
                       void* workspace, size_t workspace_bytes,
                       void* feat_nhwc_out, void* pooled_out, int pooled_dtype, float* ncp_out,
                       void* stream);
+
+int st_resnet_update_running(const st_resnet* r, const void* workspace, float* bn_running_mean, float* bn_running_var,
+                             float momentum, void* stream);
 
 int st_cast2d(const void* x, void* y, int from_dtype, int to_dtype, int rows, int cols, int ldx, int ldy, void* stream);
 

@@ -117,6 +117,7 @@ _SIGS = {
     "st_resnet_workspace_bytes": ([c_p, c_i, c_i, c_i], C.c_size_t),
     "st_resnet_forward": ([c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, C.c_size_t,
                            c_p, c_p, c_i, c_p, c_p], c_i),
+    "st_resnet_update_running": ([c_p, c_p, c_p, c_p, c_f, c_p], c_i),
 }
 
 _lib = None

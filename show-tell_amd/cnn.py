@@ -103,6 +103,7 @@ class _Backbone:
         self.packed = None
         self.packed_key = None
         self.ws = {}
+        self._upd_event = None
 
     def _ensure_handle(self):
         if self.handle is None:
@@ -179,12 +180,19 @@ class _Backbone:
             self.flatten_bn(dev)
         self.pack_weights(dev)
         B, _, H, W = x.shape
-        key = (dev, B, H, W)
+        # one workspace per (shape, stream): forwards of successive minibatches may run concurrently on different streams
+        # (train.py pipelines two of them); at most four are kept
+        cur = torch.cuda.current_stream()
+        key = (dev, B, H, W, cur.cuda_stream)
         if key not in self.ws:
             nbytes = lib().st_resnet_workspace_bytes(self.handle, B, H, W)
             if nbytes == 0:
                 raise _lib.ShowTellHipError(f"unsupported input size {tuple(x.shape)}")
-            self.ws = {key: torch.empty(nbytes, device=dev, dtype=torch.uint8)}
+            self.ws = {k: v for k, v in self.ws.items() if k[:4] == key[:4]}
+            if len(self.ws) >= 4:
+                self.ws.pop(next(iter(self.ws)))
+            with torch.cuda.stream(cur):
+                self.ws[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         ws = self.ws[key]
         F = lib().st_resnet_feat_dim(self.handle)
         ho = ((H + 6 - 7) // 2 + 1 - 1) // 2 + 1
@@ -196,11 +204,19 @@ class _Backbone:
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         fl = self.flat
         check(lib().st_resnet_forward(self.handle, p(x), B, H, W, p(self.packed), p(fl["gamma"]), p(fl["beta"]),
-                                      p(fl["rm"]), p(fl["rv"]), int(train), 0.1, 1e-5, p(ws), ws.numel(),
+                                      p(fl["rm"]), p(fl["rv"]), 2 if train else 0, 0.1, 1e-5, p(ws), ws.numel(),
                                       None, p(pooled), ST_BF16 if pooled_dtype == torch.bfloat16 else ST_F32, p(ncp),
-                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "st_resnet_forward")
+                                      C.c_void_p(cur.cuda_stream)), "st_resnet_forward")
         if train:
+            # the momentum updates of the running buffers (and num_batches_tracked) are applied in minibatch order even when
+            # the forwards themselves overlap on different streams: an event chain over the small update kernel
+            if self._upd_event is not None:
+                cur.wait_event(self._upd_event)
+            check(lib().st_resnet_update_running(self.handle, p(ws), p(fl["rm"]), p(fl["rv"]), 0.1, C.c_void_p(cur.cuda_stream)),
+                  "st_resnet_update_running")
             self.nbt.add_(1)
+            self._upd_event = torch.cuda.Event()
+            self._upd_event.record(cur)
         return pooled, ncp
 
     def __del__(self):

@@ -14,11 +14,16 @@
 //                conv epilogue together with the residual add and the ReLU.
 #include "common.h"
 #include <vector>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string.h>
 
 struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; int korder; };
 struct BlockL { int c1, c2, c3, ds; int stride; };  // indices into convs (c3 = -1 for basic blocks, ds = -1 if none)
+
+struct BnTable { int n; int end[160]; float count[160]; int soff[160]; int rep[160]; };   // soff: float offset of the layer's [rep][2C] statistics
+struct PendingUpdate { BnTable tab; const float* stats; };
 
 struct st_resnet {
   int version, dtype, bottleneck, cpad0;
@@ -26,11 +31,14 @@ struct st_resnet {
   std::vector<BlockL> blocks;
   size_t wtotal = 0, bntotal = 0;
   int feat_dim = 0;
+  // train == 2 (statistics now, running buffers later): the layer table of a forward waits here, keyed by its workspace,
+  // for st_resnet_update_running -- lets concurrent forwards on different streams apply their momentum updates in order
+  mutable std::map<const void*, PendingUpdate> pending;
+  mutable std::mutex mu;
 };
 
 namespace {
 
-struct BnTable { int n; int end[160]; float count[160]; int soff[160]; int rep[160]; };   // soff: float offset of the layer's [rep][2C] statistics
 constexpr int kStatsRepFloats = 8192;   // cap on rep * 2C per layer (what one bn_act block sums in its preamble)
 
 __global__ void bn_update_all_kernel(const float* __restrict__ stats, float* __restrict__ rm, float* __restrict__ rv,
@@ -348,10 +356,34 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   if (pooled_out && st_global_avgpool(wide[cur], pooled_out, dt, pooled_dtype, B, h * w, r->feat_dim, stream)) return 1;
   if (ncp_out && st_nhwc_to_ncp_f32(wide[cur], ncp_out, dt, B, h * w, r->feat_dim, stream)) return 1;
 
-  if (train) {
+  if (train == 2) {
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->pending[workspace] = PendingUpdate{tab, stats};
+  } else if (train) {
     hipLaunchKernelGGL(bn_update_all_kernel, dim3((total + 255) / 256), dim3(256), 0, st, stats, bn_running_mean,
                        bn_running_var, total, momentum, tab);
     ST_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// Second half of a train == 2 forward: the momentum update of every running_mean / running_var from the statistics that
+// forward left in `workspace`.  Stream-ordered after that forward by the caller; calls for successive minibatches must be
+// ordered among themselves (an event chain when the forwards run on different streams).
+extern "C" int st_resnet_update_running(const st_resnet* r, const void* workspace, float* bn_running_mean, float* bn_running_var,
+                                        float momentum, void* stream) {
+  ST_CHECK(r && workspace && bn_running_mean && bn_running_var, "st_resnet_update_running: null pointer");
+  PendingUpdate p;
+  {
+    std::lock_guard<std::mutex> lk(r->mu);
+    auto it = r->pending.find(workspace);
+    ST_CHECK(it != r->pending.end(), "st_resnet_update_running: no train == 2 forward is pending for this workspace");
+    p = it->second;
+    r->pending.erase(it);
+  }
+  const int total = (int)r->bntotal;
+  hipLaunchKernelGGL(bn_update_all_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p.stats,
+                     bn_running_mean, bn_running_var, total, momentum, p.tab);
+  ST_LAUNCH_CHECK();
   return 0;
 }

@@ -154,17 +154,23 @@ def test_pipelined_steps_equal_plain_steps():
         rnn = RNN(E, H, V, L, dtype=torch.bfloat16).cuda().train()
         opt = optim.SGD(Trainer.trainable_params(cnn, rnn), lr=0.05, momentum=0.9)
         tr = Trainer(cnn, rnn, opt)
-        batches = [synthetic_batch(B, V, seed=20 + i, image_size=128) for i in range(4)]
+        batches = [synthetic_batch(B, V, seed=20 + i, image_size=128) for i in range(5)]
         out = []
         for i, (img, cap, lens) in enumerate(batches):
             nxt = batches[i + 1][0] if (pipelined and i + 1 < len(batches)) else None
-            out.append(float(tr.step(img, cap, lens, next_image=nxt).detach()))
+            nxt2 = batches[i + 2][0] if (pipelined and i + 2 < len(batches)) else None
+            out.append(float(tr.step(img, cap, lens, next_image=nxt, next_next_image=nxt2).detach()))
         tr.flush()
         torch.cuda.synchronize()
-        return out, cnn.state_dict()["model.0.bn1.running_mean"].float().cpu() if "model.0.bn1.running_mean" in cnn.state_dict() else None
+        sd = cnn.state_dict()
+        keys = [k for k in sd if k.endswith("running_var")]
+        return out, (sd[keys[0]].float().cpu(), sd[keys[-1]].float().cpu(), int(sd[[k for k in sd if k.endswith("num_batches_tracked")][0]]))
 
     a, ra = run(False)
     b, rb = run(True)
     assert np.allclose(a, b, rtol=1e-3, atol=1e-3), (a, b)
-    if ra is not None:
-        assert torch.allclose(ra, rb, rtol=1e-4, atol=1e-5)
+    # running buffers: five momentum updates each; the stem's statistics are sums of the same bf16 products (fp32 atomics:
+    # last-bit differences), the last layer's additionally see bf16 rounding flips along 50 layers
+    assert torch.allclose(ra[0], rb[0], rtol=1e-4, atol=1e-6)
+    assert torch.allclose(ra[1], rb[1], rtol=2e-2)
+    assert ra[2] == rb[2] == 5
