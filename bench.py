@@ -110,13 +110,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # Steps are software-pipelined: the frozen backbone forwards of minibatches k+1 and k+2 are issued on two side streams
+    # Steps are software-pipelined: the frozen backbone forwards of minibatches k+1 .. k+3 are issued on side streams
     # while step k runs its trainable part (train.py).  Nothing is carried across the timing boundaries: the last warm-up
     # steps and the last timed steps prefetch nothing beyond their loop, so the timed region holds exactly `steps` complete
     # steps (the first one unpipelined, the second half-pipelined).
     pipe = not a.no_pipeline
     def ahead(k, n):   # the minibatches after step k that exist inside this loop (never across a timing boundary)
-        return dict(next_image=image if (pipe and k + 1 < n) else None, next_next_image=image if (pipe and k + 2 < n) else None)
+        return dict(upcoming=[image] * min(3, n - 1 - k) if pipe else ())
     for k in range(a.warmup):
         trainer.step(image, caption, lens, **ahead(k, a.warmup))
     trainer.flush()

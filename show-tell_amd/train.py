@@ -9,9 +9,9 @@ update are completed AFTER this step's backbone forward (which reads only frozen
 cnn.py:47) and BEFORE its trainable part.  With one GPU the order is irrelevant and the result
 is identical to the reference loop; `flush()` applies the last pending update.
 
-Software pipelining across steps (`step(..., next_image=..., next_next_image=...)`): because the backbone is frozen, the
+Software pipelining across steps (`step(..., upcoming=[next images])`): because the backbone is frozen, the
 forward of a LATER minibatch depends on nothing this step computes.  When the caller hands the next images over (a data
-loader always has them), their backbone forwards are issued on two side HIP streams and run beside this step's head /
+loader always has them), their backbone forwards are issued on side HIP streams (up to three in flight) and run beside this step's head /
 decoder / backward (launch-bound wavefront, few-tile GEMMs) AND beside each other: two backbone forwards in flight fill
 each other's launch tails and pair the HBM-bound normalise passes with the MFMA-bound convolutions (6.8 -> 5.5 ms per
 forward measured, tools/two_stream_encoder.py).  The arithmetic and its order per sample are unchanged -- the running
@@ -49,6 +49,7 @@ class Trainer:
         self._pre = []        # FIFO of (images, pooled features, event): backbone forwards issued ahead on the side streams
         self._side = []
         self._rr = 0
+        self.depth = 3        # backbone forwards kept in flight ahead of the trainable part (3 streams: 5.3 ms per forward, 2: 5.6, 1: 6.8)
 
     def trainable_params(cnn, rnn):
         """main.py:96: rnn.parameters() + cnn.linear_secondlast_layer + cnn.last_layer."""
@@ -77,8 +78,8 @@ class Trainer:
 
     def _prefetch(self, image):
         if not self._side:
-            self._side = [torch.cuda.Stream(), torch.cuda.Stream()]
-        side = self._side[self._rr % 2]
+            self._side = [torch.cuda.Stream() for _ in range(self.depth)]
+        side = self._side[self._rr % len(self._side)]
         self._rr += 1
         side.wait_stream(torch.cuda.current_stream())  # after everything already queued on the main stream
         with torch.cuda.stream(side):
@@ -87,11 +88,12 @@ class Trainer:
             ev.record(side)
         self._pre.append((image, pooled, ev))
 
-    def step(self, image, caption, caption_len, next_image=None, next_next_image=None):
+    def step(self, image, caption, caption_len, upcoming=()):
+        """One training step.  `upcoming`: the images of the next minibatches, in order (at most `depth` are used)."""
         cnn, rnn = self.cnn, self.rnn
         pooled = self._backbone(image)                 # frozen, detached (cnn.py:46-47): overlaps the all-reduce
-        # keep up to two later minibatches' frozen backbones in flight, beside this step's trainable part and each other
-        upcoming = [im for im in (next_image, next_next_image) if im is not None]
+        # keep up to `depth` later minibatches' frozen backbones in flight, beside this step's trainable part and each other
+        upcoming = [im for im in list(upcoming)[:self.depth] if im is not None]
         for j, im in enumerate(upcoming):
             if j < len(self._pre):
                 if self._pre[j][0] is not im:          # the caller changed its mind: start over from here

@@ -139,7 +139,7 @@ def test_greedy_decode_full_size_is_batch_invariant_and_matches_oracle_slice():
 
 
 def test_pipelined_steps_equal_plain_steps():
-    """Trainer.step(next_image=...) issues the next minibatch's frozen backbone on a second stream; the losses must be
+    """Trainer.step(upcoming=[...]) issues the next minibatches' frozen backbones on side streams; the losses must be
     those of the plain loop (same arithmetic; BN statistics are fp32 atomics, hence the 1e-3 tolerance)."""
     from showtell_amd import optim
     from showtell_amd.cnn import ResNet
@@ -154,12 +154,11 @@ def test_pipelined_steps_equal_plain_steps():
         rnn = RNN(E, H, V, L, dtype=torch.bfloat16).cuda().train()
         opt = optim.SGD(Trainer.trainable_params(cnn, rnn), lr=0.05, momentum=0.9)
         tr = Trainer(cnn, rnn, opt)
-        batches = [synthetic_batch(B, V, seed=20 + i, image_size=128) for i in range(5)]
+        batches = [synthetic_batch(B, V, seed=20 + i, image_size=128) for i in range(6)]
         out = []
         for i, (img, cap, lens) in enumerate(batches):
-            nxt = batches[i + 1][0] if (pipelined and i + 1 < len(batches)) else None
-            nxt2 = batches[i + 2][0] if (pipelined and i + 2 < len(batches)) else None
-            out.append(float(tr.step(img, cap, lens, next_image=nxt, next_next_image=nxt2).detach()))
+            up = [bb[0] for bb in batches[i + 1:i + 4]] if pipelined else ()
+            out.append(float(tr.step(img, cap, lens, upcoming=up).detach()))
         tr.flush()
         torch.cuda.synchronize()
         sd = cnn.state_dict()
@@ -169,8 +168,8 @@ def test_pipelined_steps_equal_plain_steps():
     a, ra = run(False)
     b, rb = run(True)
     assert np.allclose(a, b, rtol=1e-3, atol=1e-3), (a, b)
-    # running buffers: five momentum updates each; the stem's statistics are sums of the same bf16 products (fp32 atomics:
+    # running buffers: six momentum updates each; the stem's statistics are sums of the same bf16 products (fp32 atomics:
     # last-bit differences), the last layer's additionally see bf16 rounding flips along 50 layers
     assert torch.allclose(ra[0], rb[0], rtol=1e-4, atol=1e-6)
     assert torch.allclose(ra[1], rb[1], rtol=2e-2)
-    assert ra[2] == rb[2] == 5
+    assert ra[2] == rb[2] == 6

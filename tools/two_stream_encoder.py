@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from showtell_amd.cnn import ResNet
 B = 128
-ms = [ResNet(101, 512, dtype=torch.bfloat16).cuda().train() for _ in range(2)]
-xs = [torch.randn(B, 3, 224, 224, device="cuda") for _ in range(2)]
-ss = [torch.cuda.Stream(), torch.cuda.Stream()]
+NS = 4
+ms = [ResNet(101, 512, dtype=torch.bfloat16).cuda().train() for _ in range(NS)]
+xs = [torch.randn(B, 3, 224, 224, device="cuda") for _ in range(NS)]
+ss = [torch.cuda.Stream() for _ in range(NS)]
 for m, x in zip(ms, xs):
     for _ in range(2): m.backbone_features(x)
 torch.cuda.synchronize()
@@ -23,5 +24,5 @@ def run(nstream, n=12):
         torch.cuda.current_stream().wait_stream(ss[k])
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for ns in (1, 2, 1, 2):
+for ns in (1, 2, 3, 4, 2, 3):
     print(f"{ns} stream(s): {run(ns):.2f} ms per forward", flush=True)
