@@ -231,6 +231,8 @@ def main():
                                       "E=H=512, V=%d, fwd+bwd+%s step, synthetic COCO-shaped batch" % (V, a.optimizer),
                           "batch_per_gpu": B, "global_batch": B * world, "image": "3x224x224",
                           "tokens_per_batch": int(sum(lens)), "parallelism": "dp%d" % world,
+                          "schedule": ("frozen-backbone forwards of the next 3 minibatches in flight on side streams (train.py); "
+                                       "every step's full work is inside the timed region") if pipe else "plain loop (--no-pipeline)",
                           "final_loss": round(final_loss, 4)},
                "roofline": roof, "secondary": secondary}
         if world == 1 and not a.no_cpu_baseline:
