@@ -150,8 +150,20 @@ def main():
         v = max(range(8), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12 if ms[v] > 0 else 0.0
         tot_ms, tot_fl = sum(ms), sum(fl)
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process; the figure comes from the
+        # committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command
+        # (profiles/README.md; 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction), launch-weighted over the 128x128-tile forms
+        traffic = None
+        try:
+            import csv, glob
+            f = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic.csv")))[-1]
+            rows = [r for r in csv.reader(open(f)) if r and r[0].startswith("igemm_kernel<bf16,128,128,2,4,")]
+            if v == 0 and rows:
+                traffic = round(sum(float(r[1]) * float(r[4]) for r in rows) / sum(float(r[1]) for r in rows) * 1e6)
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                 "kernel": names.get(v, f"variant{v}"), "launches": int(n[v]),
                 "avg_launch_us": round(ms[v] * 1e3 / max(1, n[v]), 2),
                 "all_igemm_TFLOPs": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,

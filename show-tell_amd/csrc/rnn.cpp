@@ -30,7 +30,7 @@ inline int up8(int v) { return (v + 7) & ~7; }
 struct Plan {
   int G, GH, Np, Vp, maxw;
   size_t es;
-  size_t x0, y, gates, cst, dyl, dx0, dgx, dgh, dhc, dcc, hprev, tA, tB, wT, wThh, wTih, gA, gB, total;
+  size_t x0, y, gates, cst, dyl, dx0, dgx, dgh, dhc, dcc, tA, tB, wT, wThh, wTih, gA, gB, total;
 };
 
 Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
@@ -54,7 +54,6 @@ Plan make_plan(const st_rnn_params* p, const st_packed_seq* s) {
   q.dgh = take(p->cell == ST_CELL_GRU ? L * n * q.GH * q.es : 0);
   q.dhc = take(L * (size_t)s->B * H * sizeof(float));
   q.dcc = take(L * (size_t)s->B * H * sizeof(float));
-  q.hprev = take(n * H * q.es);
   // transposed operands: tA <= max(V, GH) x Np ; tB <= max(H, in0) x Np ; wT <= max(H x Vp, maxw x GH)
   const size_t ra = (size_t)(p->V > q.GH ? p->V : q.GH);
   q.tA = take(ra * q.Np * q.es);
