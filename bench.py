@@ -227,6 +227,35 @@ def main():
                          "greedy_captions_per_sec": round(B / (us_step * 25e-6), 0),
                          "beam5_bs256_captions_per_sec": round(256 / tb, 0)}
             rnn.train()
+            # BASELINE configs[2]: soft-attention GRU decoder (Attention/main_attn.py), bs=64, alpha_c=1.0: train steps/sec
+            try:
+                from showtell_amd.cnn_attn import ResNet as ResNetAttn
+                from showtell_amd.rnn_attn import RNN_Attn
+                cnn_a = ResNetAttn(101, E, dtype=dtype).to(dev).train()
+                rnn_a = RNN_Attn(E, 2048, 512, H, V, L, dtype=dtype).to(dev).train()
+                opt_a = optim.SGD(list(rnn_a.parameters()), lr=0.01, momentum=0.9)
+                img_a, cap_a, lens_a = synthetic_batch(64, V, seed=5, device=dev)
+
+                def astep():
+                    opt_a.zero_grad()
+                    la = rnn_a.loss(cnn_a(img_a), cap_a, lens_a, 1.0)      # main_attn.py:126-131
+                    la.backward()
+                    opt_a.step()
+                    return la
+                for _ in range(3):
+                    astep()
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(8):
+                    la = astep()
+                torch.cuda.synchronize()
+                ta = (time.perf_counter() - ta) / 8
+                secondary["attention_gru_bs64_train_images_per_sec"] = round(64 / ta, 1)
+                secondary["attention_gru_bs64_ms_per_step"] = round(ta * 1e3, 3)
+                secondary["attention_gru_bs64_loss_finite"] = bool(torch.isfinite(la.detach()).item())
+                del cnn_a, rnn_a, opt_a
+            except Exception as e:
+                secondary["attention_error"] = repr(e)
         except Exception as e:
             secondary = {"error": repr(e)}
     if world > 1:
