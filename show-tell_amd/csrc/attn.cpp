@@ -105,6 +105,16 @@ int skinny(const void* A, int lda, const void* W, int ldw, float* out, int ldo, 
   return rnn_gemm_launch(a, dtype, 0, 0, st);
 }
 
+// y[M][ldy] (storage dtype) = A W^T + bias through the skinny kernel: for the per-step context embedding ([B_t x F] x [F x E],
+// K = 2048): 4 output tiles of a 128x128 MFMA tile walk K for ~37 us, 128 blocks of 16x16 with K split over 4 waves for ~10
+int skinny_t(const void* A, int lda, const void* W, int ldw, void* y, int ldy, int M, int N, int K, const float* bias, int dtype, hipStream_t st) {
+  RnnGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.gstride = 0;
+  a.hout = y; a.ldho = ldy; a.bias_h = bias;
+  return rnn_gemm_launch(a, dtype, 0, 0, st);
+}
+
 int check_common(const st_attn_params* p, const st_packed_seq* s, const char* who) {
   ST_CHECK(p, "%s: null descriptor", who);
   const st_rnn_params& r = p->rnn;
@@ -177,7 +187,7 @@ extern "C" int st_attn_forward(const st_attn_params* p, const st_packed_seq* s, 
     if (skinny(htop_prev, H, p->w_dec, H, att2, A, bt, A, H, p->b_dec, 0, dt, st)) return 1;
     if (attn_fwd_launch(ws + q.att1, att2, p->w_full, p->b_full, ws + q.feat, alphas + (size_t)t * P, (long)s->Tcap * P, zt, bt, P, A, F, dt, st)) return 1;
     if (st_embedding_rows(r.emb, caption_T + (size_t)t * B, xt, bt, E, r.V, 2 * E, dt, stream)) return 1;
-    if (gemm_nt(zt, F, p->w_embed, F, xt + (size_t)E * es, 2 * E, bt, E, F, dt, dt, p->b_embed, 0, stream)) return 1;
+    if (skinny_t(zt, F, p->w_embed, F, xt + (size_t)E * es, 2 * E, bt, E, F, p->b_embed, dt, st)) return 1;
     for (int l = 0; l < L; ++l) {
       char* yl = ws + q.y + (size_t)l * n * H * es;
       RnnGemmArgs a;
@@ -421,7 +431,7 @@ extern "C" int st_attn_greedy(const st_attn_params* p, const float* cnn_feature,
     if (skinny(htop, H, p->w_dec, H, att2, A, B, A, H, p->b_dec, 0, dt, st)) return 1;
     if (attn_fwd_launch(ws + q.att1, att2, p->w_full, p->b_full, ws + q.feat, alpha_scratch, P, ws + q.z, B, P, A, F, dt, st)) return 1;
     if (st_embedding_rows(r.emb, cur, ws + q.x, B, E, r.V, 2 * E, dt, stream)) return 1;
-    if (gemm_nt(ws + q.z, F, p->w_embed, F, ws + q.x + (size_t)E * es, 2 * E, B, E, F, dt, dt, p->b_embed, 0, stream)) return 1;
+    if (skinny_t(ws + q.z, F, p->w_embed, F, ws + q.x + (size_t)E * es, 2 * E, B, E, F, p->b_embed, dt, st)) return 1;
     if (st_rnn_step(&r, ws + q.x, B, ws + q.h[c], ws + q.c[c], ws + q.h[nx], ws + q.c[nx], logits, Vp, stream)) return 1;
     hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, st, logits, Vp, r.V, ids_out, steps, t, cur);
     ST_LAUNCH_CHECK();

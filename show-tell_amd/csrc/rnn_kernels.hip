@@ -225,11 +225,11 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
     return;
   }
   if (EPI == 0) {
-    float* o = a.out_f32 + (long)m * a.ldo + n;
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = sumH[0][e] + eb[0][e] + es[e];
-    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    if (a.hout) store4<T>(reinterpret_cast<T*>(a.hout) + (long)m * a.ldho + n, v);      // output in the storage type (ldho)
+    else *reinterpret_cast<f32x4*>(a.out_f32 + (long)m * a.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
   } else if (EPI == 1) {
     // r,z,n order (torch.nn.GRU): r = s(xr+hr), z = s(xz+hz), n = tanh(xn + r*(hn)), h' = (1-z) n + z h
     float xg[3][4];
