@@ -190,6 +190,7 @@ class _Backbone:
                 raise _lib.ShowTellHipError(f"unsupported input size {tuple(x.shape)}")
             self.ws = {k: v for k, v in self.ws.items() if k[:4] == key[:4]}
             if len(self.ws) >= 4:
+                torch.cuda.synchronize(dev)             # rare: the evicted workspace may still be in use on its stream
                 self.ws.pop(next(iter(self.ws)))
             with torch.cuda.stream(cur):
                 self.ws[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
