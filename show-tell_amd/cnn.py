@@ -188,7 +188,9 @@ class _Backbone:
             nbytes = lib().st_resnet_workspace_bytes(self.handle, B, H, W)
             if nbytes == 0:
                 raise _lib.ShowTellHipError(f"unsupported input size {tuple(x.shape)}")
-            self.ws = {k: v for k, v in self.ws.items() if k[:4] == key[:4]}
+            if any(k[:4] != key[:4] for k in self.ws):   # another input shape: its workspaces go (after their streams drained)
+                torch.cuda.synchronize(dev)
+                self.ws = {k: v for k, v in self.ws.items() if k[:4] == key[:4]}
             if len(self.ws) >= 4:
                 torch.cuda.synchronize(dev)             # rare: the evicted workspace may still be in use on its stream
                 self.ws.pop(next(iter(self.ws)))
