@@ -61,3 +61,25 @@ def test_beam_search_full_size_matches_oracle_and_is_batch_invariant():
     assert nonempty >= 3
     sub = m.beam_search(feat[3:7].cuda(), beam_width=5, num_hypotheses=1, max_length=25)
     assert [h[0][0] if h else None for h in sub] == [h[0][0] if h else None for h in got[3:7]]
+
+
+def test_bf16_greedy_bleu4_vs_fp32_oracle():
+    """BASELINE config 5 quality gate at the full decoder shape: 25-token greedy captions of the bf16 kernels against the fp32
+    CPU oracle (rnn.py:37-58) on the same weights, scored with the reference's BLEU (corpus BLEU-4 >= 0.9: random-init
+    weights make near-ties common, bf16 rounding flips a few tokens); the fp32 kernels must give the oracle's ids exactly."""
+    from showtell_amd.rnn import RNN
+    E = H = 512
+    L, V = 5, 10000
+    sd = R.init_decoder_params(E, H, V, L, "gru", seed=6)
+    sd["linear.weight"] *= 12.0
+    sd["linear.bias"][2] += 1.5
+    fq = torch.randn(8, E, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        g_ref = R.rnn_greedy(sd, fq)
+    r32 = RNN(E, H, V, L, dtype=torch.float32); r32.load_state_dict(sd); r32 = r32.cuda().eval()
+    r16 = RNN(E, H, V, L, dtype=torch.bfloat16); r16.load_state_dict(sd); r16 = r16.cuda().eval()
+    assert torch.equal(r32.sentence_index(fq.cuda()).cpu(), g_ref)
+    g_hip = r16.sentence_index(fq.cuda()).cpu()
+    gts = {str(b): [" ".join(map(str, g_ref[b].tolist()))] for b in range(8)}
+    res = {str(b): [" ".join(map(str, g_hip[b].tolist()))] for b in range(8)}
+    assert R.bleu_corpus(gts, res, 4)[3] >= 0.9
