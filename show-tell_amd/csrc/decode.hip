@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void vocab_argmax_lds_kernel(const T* __restri
   for (int e = 0; e < 4; ++e) bz[e] = n + e < N ? bias[n + e] : 0.f;
   const int cpr = K / EPC;                              // 16-byte chunks per row (multiple of 8: host check)
   const int rowb = K * (int)sizeof(T);
-  for (int mb = 0; mb < M; mb += rows_per_pass) {
+  for (int mb = blockIdx.y * rows_per_pass; mb < M; mb += gridDim.y * rows_per_pass) {   // grid.y splits the rows when entries alone leave CUs idle
     const int rows = min(rows_per_pass, M - mb);
     __syncthreads();                                    // previous pass has left the buffer
     // 8 chunks per thread in flight: the staging pass is one or two L2 round trips, not one per chunk
@@ -376,6 +376,8 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
       const int epc = dt == ST_BF16 ? 8 : 4;
       int rpp = (int)((128 * 1024) / ((size_t)H * es)) & ~15;
       if (rpp > ((B + 15) & ~15)) rpp = (B + 15) & ~15;
+      int ysplit = 1;                                   // V/64 blocks alone fill 157 of 256 CUs at V = 10000: split the rows too
+      while ((V + 63) / 64 * ysplit < 256 && rpp >= 32 && rpp % 32 == 0 && ysplit < 4) { ysplit *= 2; rpp /= 2; }
       if (H <= 64 * epc && H % (8 * epc) == 0 && rpp >= 16) {
         // LDS-staged form: activations once per block, projection matrix once chip-wide
         const size_t lds = (size_t)rpp * H * es + (size_t)4 * rpp * sizeof(unsigned long long);
@@ -385,7 +387,7 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_argmax_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           attr_set = true;
         }
-        const dim3 vgrid((V + 63) / 64);
+        const dim3 vgrid((V + 63) / 64, ysplit);
         if (dt == ST_BF16)
           hipLaunchKernelGGL(vocab_argmax_lds_kernel<bf16_t>, vgrid, dim3(256), lds, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, keys, rpp);
         else
