@@ -63,6 +63,25 @@ def cpu_baseline(threads, B=8, budget_s=12.0):
     return B * steps / dt, dt, steps
 
 
+def _corpus_bleu4(refs, hyps):
+    """Corpus BLEU-4 (uniform weights, brevity penalty) over token-id sequences, one reference per hypothesis."""
+    import math
+    from collections import Counter
+    num, den = [0] * 4, [0] * 4
+    rl = hl = 0
+    for r, h in zip(refs, hyps):
+        rl += len(r); hl += len(h)
+        for n in range(1, 5):
+            rc = Counter(tuple(r[i:i + n]) for i in range(len(r) - n + 1))
+            hc = Counter(tuple(h[i:i + n]) for i in range(len(h) - n + 1))
+            num[n - 1] += sum(min(c, rc[g]) for g, c in hc.items())
+            den[n - 1] += max(0, len(h) - n + 1)
+    if min(num) == 0 or min(den) == 0:
+        return 0.0
+    bp = 1.0 if hl >= rl else math.exp(1.0 - rl / max(1, hl))
+    return bp * math.exp(sum(math.log(a / b) for a, b in zip(num, den)) / 4.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,7 +233,21 @@ def main():
                 same32 += int((h32[b_][0][0] if h32[b_] else []) == ref_seq)
                 same16 += int((h16[b_][0][0] if h16[b_] else []) == ref_seq)
             del r32, r16
+            # BLEU-4 of 25-token greedy captions against the reference's own greedy captions (tests/golden/gru_small.npz, rnn.py:37-58)
+            gg = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "gru_small.npz"))
+            gq = {k[2:]: torch.from_numpy(gg[k]) for k in gg.files if k.startswith("p/")}
+            qV, qE = gq["embeddings.weight"].shape
+            qH = gq["unit.weight_hh_l0"].shape[1]
+            qL = sum(1 for k in gq if k.startswith("unit.weight_hh_l"))
+            bleu = {}
+            for nm_, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+                rq = RNN(qE, qH, qV, qL, dtype=dt_); rq.load_state_dict(gq); rq = rq.to(dev).eval()
+                hyp = rq.sentence_index(torch.from_numpy(gg["feat"]).to(dev)).cpu().numpy()
+                bleu[nm_] = _corpus_bleu4([list(map(int, r_)) for r_ in gg["greedy"]], [list(map(int, h_)) for h_ in hyp])
+                del rq
             secondary = {"greedy_decode_us_per_step": round(us_step, 1),
+                         "greedy_fp32_bleu4_vs_reference_vectors": round(bleu["fp32"], 4),
+                         "greedy_bf16_bleu4_vs_reference_vectors": round(bleu["bf16"], 4),
                          "beam5_fp32_id_match_vs_reference_vectors": round(same32 / max(1, nimg), 3),
                          "beam5_bf16_id_match_vs_reference_vectors": round(same16 / max(1, nimg), 3),
                          "beam5_reference_vectors_images": nimg, "beam5_reference_nonempty": nonempty,
