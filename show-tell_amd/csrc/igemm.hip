@@ -489,6 +489,159 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmGroup grp) {
 #undef ST_STAMP
 }
 
+// =======================================================================================
+// Main loop 2 (bf16, Cin % 64 == 0, no input transform): the "many small blocks" form.  128x128 tile, 4 waves (64x64 per
+// wave), ONE 32 KiB K-tile buffer filled by LDS-DMA (global_load_lds, 16 B per lane; lane-linear image, bank swizzle on the
+// per-lane source chunk and on the reads; padding taps / ragged rows read a zero word), two barriers per K tile:
+//   DMA tile k -> vmcnt(0) -> barrier -> 16 ds_read_b128 + 32 MFMA per wave -> barrier.
+// Nothing overlaps inside a block; 3-4 blocks per CU (36 KiB of LDS, no staging registers) overlap each other instead.
+// =======================================================================================
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+__global__ __launch_bounds__(256) void igemm_s3_kernel(IgemmGroup grp) {
+  typedef bf16_t T;
+  const IgemmArgs& a = grp.g[blockIdx.y];
+  if ((int)blockIdx.x >= a.nbm * a.nbn) return;
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 2, NW = 4;
+  constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);     // 1-KiB pieces (8 rows) per wave per tile: 4 + 4
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;       // 4 x 4 MFMA tiles per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = a.nbm * a.nbn;
+  int lid;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int bm = lid / a.nbn, bn = lid - bm * a.nbn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid - wm * WN;
+
+  const int prow = lane >> 3, ccol = (lane & 7) ^ prow;     // lane -> (row of an 8-row piece, source chunk)
+  const char* Zp = reinterpret_cast<const char*>(g_zero16);
+  const char* arow[PA];
+  unsigned long long amask[PA];
+  const char* pb[PB]; int sb[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int n = bn * BN + (wid + NW * i) * 8 + prow;
+    const bool ok = n < a.N;
+    pb[i] = ok ? reinterpret_cast<const char*>(a.w) + ((long)n * a.ldw + ccol * 8) * 2 : Zp;
+    sb[i] = ok ? 128 : 0;
+  }
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = bm * BM + (wid + NW * i) * 8 + prow;
+    arow[i] = Zp; amask[i] = 0ull;
+    if (m < a.M) {
+      const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+      arow[i] = reinterpret_cast<const char*>(a.x) + ((long)(b * a.Hin * a.Win + hi0 * a.Win + wi0) * a.ldx + ccol * 8) * 2;
+      const int h0 = hi0 < 0 ? -hi0 : 0, h1 = a.Hin - hi0 < a.KH ? a.Hin - hi0 : a.KH;
+      const int w0 = wi0 < 0 ? -wi0 : 0, w1 = a.Win - wi0 < a.KW ? a.Win - wi0 : a.KW;
+      if (h1 > h0 && w1 > w0) {
+        const unsigned long long wmk = ((1ull << w1) - 1ull) & ~((1ull << w0) - 1ull);
+        for (int fh = h0; fh < h1; ++fh) amask[i] |= wmk << (fh * a.KW);
+      }
+    }
+  }
+  const int ntap = a.KH * a.KW, nchunk = a.Cin >> 6;
+  int tap = 0, kh = 0, kw = 0, chunk = 0;
+  const char* pa[PA]; int sa[PA];
+  auto retap = [&]() {
+    const long off = ((long)(kh * a.Win + kw) * a.ldx + chunk * 64) * 2;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const bool ok = (amask[i] >> tap) & 1ull;
+      pa[i] = ok ? arow[i] + off : Zp;
+      sa[i] = ok ? 128 : 0;
+    }
+  };
+  retap();
+  auto issue = [&]() {
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)pa[i], (lptr_t)(smem + (wid + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)pb[i], (lptr_t)(smem + BM * 128 + (wid + NW * i) * 1024), 16, 0, 0);
+    if (a.korder) {
+      ++tap; if (++kw == a.KW) { kw = 0; ++kh; }
+      if (tap == ntap) { tap = 0; kh = 0; kw = 0; ++chunk; }
+      retap();
+    } else if (++chunk == nchunk) {
+      chunk = 0; ++tap; if (++kw == a.KW) { kw = 0; ++kh; }
+      retap();
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) pa[i] += sa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) pb[i] += sb[i];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int nk = a.K >> 6;
+  const int arow_off = (wm * (BM / WM) + r16) * 128, brow_off = (BM + wn * (BN / WN) + r16) * 128;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    issue();
+    __syncthreads();                                   // emits vmcnt(0): the tile has landed, for every wave
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ((ks * 4 + q4) ^ (r16 & 7)) << 4;
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(smem + brow_off + j * 2048 + so);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + arow_off + i * 2048 + so);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+    }
+    __syncthreads();                                   // everybody is done reading before the next DMA overwrites
+  }
+  igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
+}
+
+int launch_s3(IgemmArgs* arr, int n, hipStream_t st) {
+  IgemmArgs& a = arr[0];
+  IgemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  for (int i = 0; i < n; ++i) {
+    arr[i].nbm = (arr[i].M + 127) / 128;
+    arr[i].nbn = (arr[i].N + 127) / 128;
+    grp.g[i] = arr[i];
+  }
+  constexpr int lds = 64 * (128 + 4) * 4 + 2 * 128 * 2 * 4;   // the epilogue's staging rows + statistics partials (> the 32 KiB K tile)
+  ProfRec rec; bool prof = false;
+  if (g_prof_on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.size() < kProfMax && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
+      rec.variant = 0; rec.flops = a.flops * n; prof = true;
+      (void)hipEventRecord(rec.e0, st);
+    }
+  }
+  hipLaunchKernelGGL(igemm_s3_kernel, dim3(a.nbm * a.nbn, n), dim3(256), lds, st, grp);
+  if (prof) {
+    (void)hipEventRecord(rec.e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(rec);
+  }
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int KC, int MODE>
 int launch_(IgemmArgs* arr, int n, hipStream_t st) {
   IgemmArgs& a = arr[0];
@@ -566,6 +719,15 @@ int dispatch_kc(IgemmArgs* arr, int n, hipStream_t st) {
 template <typename T>
 int dispatch(IgemmArgs* arr, int n, hipStream_t st) {
   IgemmArgs& a = arr[0];
+  // EXPERIMENTAL, off by default (ST_IGEMM_S3=1 / st_tune(1,..) routes every legal problem to it, =3 only the 3x3 layers with
+  // >= 256 channels and >= 256 tiles): the many-small-blocks form is 15-18 % faster than the 8-wave kernel on the 3x3 256->256
+  // @14x14 layer in isolation (47 vs 55 us back to back, 50 vs 56 behind a bn_act launch) but 6 us SLOWER inside the network
+  // (59 vs 53 us per launch in the rocprof trace of a forward; encoder 7.00 vs 6.79 ms) -- unexplained, see DESIGN.md
+  const int s3 = tuning_get(0, "ST_IGEMM_S3");
+  const bool s3_legal = sizeof(T) == 2 && a.Cin % 64 == 0 && a.K % 64 == 0 && a.KH * a.KW <= 64 && !a.in_stats && a.N > 64 && a.ldx >= a.Cin;
+  const long s3_tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (s3_legal && (s3 == 1 || (s3 == 3 && a.KH * a.KW > 1 && a.Cin >= 256 && s3_tiles >= 256)))
+    return launch_s3(arr, n, st);
   // 64-byte tile rows halve the LDS footprint (3-4 blocks per CU instead of 2): the short-K pointwise layers
   // (K <= 256: 4 K steps or fewer, prologue/epilogue-bound) gain 8-15 % from the extra overlap, long-K layers lose.
   const int kc = tuning_kc();

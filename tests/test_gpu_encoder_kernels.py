@@ -308,6 +308,35 @@ def test_split_k_gemm(dtype, M, N, K, S, acc):
     assert (one - out).abs().max().item() <= 1e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(2, 14, 14, 256, 256, 3, 1, 1), (2, 28, 28, 128, 128, 3, 2, 1), (3, 14, 14, 1024, 256, 1, 1, 0), (1, 9, 11, 64, 136, 3, 1, 1)])
+def test_experimental_small_block_kernel_matches_conv2d(case):
+    """The opt-in LDS-DMA "many small blocks" main loop (ST_IGEMM_S3 / st_tune(1, ..)) computes the same convolution
+    and statistics as the default kernel (bf16; padding taps and ragged edges go through the zero word)."""
+    ops = _ops()
+    from showtell_amd._lib import lib
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)).bfloat16().float()
+    ref = F.conv2d(x, w, None, s, p).permute(0, 2, 3, 1).contiguous()
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", torch.bfloat16)
+    try:
+        for ko in (0, 1) if k > 1 else (0,):
+            wd = ops.pack_conv_weight(w.cuda(), torch.bfloat16, k_order=ko)
+            lib().st_tune(0, -1, -1)
+            s0 = torch.zeros(2 * Cout, device="cuda")
+            y0 = ops.conv_nhwc(xd, wd, k, k, s, p, stats=s0, k_order=ko)
+            lib().st_tune(1, -1, -1)
+            s1 = torch.zeros(2 * Cout, device="cuda")
+            y1 = ops.conv_nhwc(xd, wd, k, k, s, p, stats=s1, k_order=ko)
+            torch.cuda.synchronize()
+            _close(y1, ref, torch.bfloat16, "small-block conv")
+            assert (y0.float() - y1.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+            np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-3, atol=0.5)
+    finally:
+        lib().st_tune(0, -1, -1)
+
+
 def test_bn_update_running_matches_torch():
     ops = _ops()
     g = torch.Generator().manual_seed(9)
