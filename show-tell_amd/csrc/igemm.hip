@@ -722,7 +722,8 @@ int dispatch(IgemmArgs* arr, int n, hipStream_t st) {
   // EXPERIMENTAL, off by default (ST_IGEMM_S3=1 / st_tune(1,..) routes every legal problem to it, =3 only the 3x3 layers with
   // >= 256 channels and >= 256 tiles): the many-small-blocks form is 15-18 % faster than the 8-wave kernel on the 3x3 256->256
   // @14x14 layer in isolation (47 vs 55 us back to back, 50 vs 56 behind a bn_act launch) but 6 us SLOWER inside the network
-  // (59 vs 53 us per launch in the rocprof trace of a forward; encoder 7.00 vs 6.79 ms) -- unexplained, see DESIGN.md
+  // (59 vs 53 us per launch in the rocprof trace of a forward; encoder 7.00 vs 6.79 ms): with cold per-layer weights a block
+  // that overlaps nothing internally pays every K tile's miss latency in full, see DESIGN.md
   const int s3 = tuning_get(0, "ST_IGEMM_S3");
   const bool s3_legal = sizeof(T) == 2 && a.Cin % 64 == 0 && a.K % 64 == 0 && a.KH * a.KW <= 64 && !a.in_stats && a.N > 64 && a.ldx >= a.Cin;
   const long s3_tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
