@@ -614,7 +614,136 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(IgemmGroup grp) {
   igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
 }
 
-int launch_s3(IgemmArgs* arr, int n, hipStream_t st) {
+// Same block shape with DMA tiles in flight ACROSS the barrier: three 16 KiB buffers of 32-deep K tiles (A 128x64 B + B 128x64 B),
+// tile kt+2 is issued right after the barrier that publishes tile kt, one raw barrier per K tile, counted vmcnt.
+// 48 KiB of LDS -> still 3 blocks per CU.  Lane-linear image of 64-byte rows: one DMA instruction = 16 rows x 4 chunks,
+// LDS slot s of row r holds source chunk s ^ ((r >> 1) & 3) (conflict-free ds_read_b128 over 16 rows x 1 chunk... see read side).
+template <int N> __device__ __forceinline__ void s3_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(256) void igemm_s3b_kernel(IgemmGroup grp) {
+  typedef bf16_t T;
+  const IgemmArgs& a = grp.g[blockIdx.y];
+  if ((int)blockIdx.x >= a.nbm * a.nbn) return;
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 2, NW = 4, NB = 3;
+  constexpr int PA = BM / (16 * NW), PB = BN / (16 * NW);   // 1-KiB pieces (16 rows x 64 B) per wave per tile: 2 + 2
+  constexpr int G = PA + PB;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int TILE_BYTES = (BM + BN) * 64;                // 16 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = a.nbm * a.nbn;
+  int lid;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int bm = lid / a.nbn, bn = lid - bm * a.nbn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid - wm * WN;
+
+  // lane -> (row of a 16-row piece, LDS slot); the slot receives source chunk slot ^ swz(row)
+  const int prow = lane >> 2, slot = lane & 3;
+  const int ccol = slot ^ ((prow >> 1) & 3);
+  const char* Zp = reinterpret_cast<const char*>(g_zero16);
+  const char* arow[PA];
+  unsigned long long amask[PA];
+  const char* pb[PB]; int sb[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int n = bn * BN + (wid + NW * i) * 16 + prow;
+    const bool ok = n < a.N;
+    pb[i] = ok ? reinterpret_cast<const char*>(a.w) + ((long)n * a.ldw + ccol * 8) * 2 : Zp;
+    sb[i] = ok ? 64 : 0;
+  }
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = bm * BM + (wid + NW * i) * 16 + prow;
+    arow[i] = Zp; amask[i] = 0ull;
+    if (m < a.M) {
+      const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+      arow[i] = reinterpret_cast<const char*>(a.x) + ((long)(b * a.Hin * a.Win + hi0 * a.Win + wi0) * a.ldx + ccol * 8) * 2;
+      const int h0 = hi0 < 0 ? -hi0 : 0, h1 = a.Hin - hi0 < a.KH ? a.Hin - hi0 : a.KH;
+      const int w0 = wi0 < 0 ? -wi0 : 0, w1 = a.Win - wi0 < a.KW ? a.Win - wi0 : a.KW;
+      if (h1 > h0 && w1 > w0) {
+        const unsigned long long wmk = ((1ull << w1) - 1ull) & ~((1ull << w0) - 1ull);
+        for (int fh = h0; fh < h1; ++fh) amask[i] |= wmk << (fh * a.KW);
+      }
+    }
+  }
+  // walk in 32-channel steps; k_order 0: tap outer / channels inner, k_order 1: 64-channel chunk outer, tap inner (two steps per tap visit)
+  const int ntap = a.KH * a.KW;
+  int tap = 0, kh = 0, kw = 0, c32 = 0;                      // c32: 32-channel step index inside the current (tap | chunk) run
+  const int run = a.korder ? 2 : (a.Cin >> 5);               // steps before the tap changes
+  int chunk = 0;                                             // k_order 1: current 64-channel chunk
+  const char* pa[PA]; int sa[PA];
+  auto retap = [&]() {
+    const long off = ((long)(kh * a.Win + kw) * a.ldx + (a.korder ? chunk * 64 : 0)) * 2;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const bool ok = (amask[i] >> tap) & 1ull;
+      pa[i] = ok ? arow[i] + off : Zp;
+      sa[i] = ok ? 64 : 0;
+    }
+  };
+  retap();
+  auto issue = [&](char* base) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)pa[i], (lptr_t)(base + (wid + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)pb[i], (lptr_t)(base + BM * 64 + (wid + NW * i) * 1024), 16, 0, 0);
+    if (++c32 == run) {
+      c32 = 0;
+      ++tap; if (++kw == a.KW) { kw = 0; ++kh; }
+      if (a.korder && tap == ntap) { tap = 0; kh = 0; kw = 0; ++chunk; }
+      retap();
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) pa[i] += sa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) pb[i] += sb[i];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int nk = a.K >> 5;                                  // 32-deep K tiles (K % 64 == 0)
+  // fragment read: row = base + r16, chunk q4 -> slot q4 ^ ((row >> 1) & 3)   (row bases are multiples of 16)
+  const int so = (q4 ^ ((r16 >> 1) & 3)) << 4;
+  const int arow_off = (wm * (BM / WM) + r16) * 64 + so, brow_off = (BM + wn * (BN / WN) + r16) * 64 + so;
+
+  issue(smem);
+  issue(smem + TILE_BYTES);                                  // nk >= 2
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) s3_wait_vmcnt<G>(); else s3_wait_vmcnt<0>();   // tile kt has landed (this wave's pieces)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave is done reading tile kt-1
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) issue(smem + ((kt + 2) % NB) * TILE_BYTES);   // refill the buffer of tile kt-1
+    const char* cur = smem + (kt % NB) * TILE_BYTES;
+    u32x4 fa[TM], fb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(cur + brow_off + j * 1024);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(cur + arow_off + i * 1024);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+  }
+  __syncthreads();
+  igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
+}
+
+int launch_s3(IgemmArgs* arr, int n, hipStream_t st, bool pipelined = false) {
   IgemmArgs& a = arr[0];
   IgemmGroup grp;
   memset(&grp, 0, sizeof(grp));
@@ -623,7 +752,7 @@ int launch_s3(IgemmArgs* arr, int n, hipStream_t st) {
     arr[i].nbn = (arr[i].N + 127) / 128;
     grp.g[i] = arr[i];
   }
-  constexpr int lds = 64 * (128 + 4) * 4 + 2 * 128 * 2 * 4;   // the epilogue's staging rows + statistics partials (> the 32 KiB K tile)
+  const int lds = pipelined ? 3 * 256 * 64 : 64 * (128 + 4) * 4 + 2 * 128 * 2 * 4;   // 3 K tiles | the epilogue's staging rows + statistics partials
   ProfRec rec; bool prof = false;
   if (g_prof_on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -632,7 +761,8 @@ int launch_s3(IgemmArgs* arr, int n, hipStream_t st) {
       (void)hipEventRecord(rec.e0, st);
     }
   }
-  hipLaunchKernelGGL(igemm_s3_kernel, dim3(a.nbm * a.nbn, n), dim3(256), lds, st, grp);
+  if (pipelined) hipLaunchKernelGGL(igemm_s3b_kernel, dim3(a.nbm * a.nbn, n), dim3(256), lds, st, grp);
+  else hipLaunchKernelGGL(igemm_s3_kernel, dim3(a.nbm * a.nbn, n), dim3(256), lds, st, grp);
   if (prof) {
     (void)hipEventRecord(rec.e1, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -729,6 +859,12 @@ int dispatch(IgemmArgs* arr, int n, hipStream_t st) {
   const long s3_tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   if (s3_legal && (s3 == 1 || (s3 == 3 && a.KH * a.KW > 1 && a.Cin >= 256 && s3_tiles >= 256)))
     return launch_s3(arr, n, st);
+  // The three-buffer form is the default for long-K layers with enough tiles (K >= 1024, >= 256 input channels, >= 256 tiles:
+  // the 14x14 conv1 / conv2 layers of ResNet-101): 145 -> 136 us per bottleneck block in tools/chain_bench.py.  4: everywhere
+  // legal, 5: only the 3x3 layers, 2: never.
+  if (s3_legal && a.K >= 128 && s3 != 2 &&
+      (s3 == 4 || (s3 == 5 && a.KH * a.KW > 1 && a.Cin >= 256 && s3_tiles >= 256) || (s3 == 0 && a.K >= 1024 && a.Cin >= 256 && s3_tiles >= 256)))
+    return launch_s3(arr, n, st, true);
   // 64-byte tile rows halve the LDS footprint (3-4 blocks per CU instead of 2): the short-K pointwise layers
   // (K <= 256: 4 K steps or fewer, prologue/epilogue-bound) gain 8-15 % from the extra overlap, long-K layers lose.
   const int kc = tuning_kc();

@@ -326,13 +326,14 @@ def test_experimental_small_block_kernel_matches_conv2d(case):
             lib().st_tune(0, -1, -1)
             s0 = torch.zeros(2 * Cout, device="cuda")
             y0 = ops.conv_nhwc(xd, wd, k, k, s, p, stats=s0, k_order=ko)
-            lib().st_tune(1, -1, -1)
-            s1 = torch.zeros(2 * Cout, device="cuda")
-            y1 = ops.conv_nhwc(xd, wd, k, k, s, p, stats=s1, k_order=ko)
-            torch.cuda.synchronize()
-            _close(y1, ref, torch.bfloat16, "small-block conv")
-            assert (y0.float() - y1.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
-            np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-3, atol=0.5)
+            for variant in (1, 4):                       # single-buffer and three-buffer forms
+                lib().st_tune(variant, -1, -1)
+                s1 = torch.zeros(2 * Cout, device="cuda")
+                y1 = ops.conv_nhwc(xd, wd, k, k, s, p, stats=s1, k_order=ko)
+                torch.cuda.synchronize()
+                _close(y1, ref, torch.bfloat16, "small-block conv")
+                assert (y0.float() - y1.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+                np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-3, atol=0.5)
     finally:
         lib().st_tune(0, -1, -1)
 
