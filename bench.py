@@ -165,7 +165,7 @@ def main():
         ms, fl, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_long * 8)()
         lib().st_prof_collect(ms, fl, n)
         lib().st_prof_enable(0)
-        names = {0: "igemm_kernel<bf16,128,128,2,4,8>", 1: "igemm_kernel<bf16,128,64,4,1,8>", 2: "igemm_kernel<bf16,64,128,1,4,8>", 3: "igemm_kernel<bf16,256,128,4,2,8>"}
+        names = {0: "128x128-tile igemm family: igemm_kernel<bf16,128,128,2,4,{8,4},{1,2}> + igemm_s3b_kernel", 1: "igemm_kernel<bf16,128,64,4,1,8>", 2: "igemm_kernel<bf16,64,128,1,4,8>", 3: "igemm_kernel<bf16,256,128,4,2,8>"}
         v = max(range(8), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12 if ms[v] > 0 else 0.0
         tot_ms, tot_fl = sum(ms), sum(fl)
