@@ -136,6 +136,28 @@ int st_maxpool3x3s2_bn(const void* x, void* y, int dtype, int B, int H, int W, i
 /* global average pool NHWC -> [B][C] (adaptive avgpool, cnn.py:34) */
 int st_global_avgpool(const void* x, void* y, int dtype, int out_dtype, int B, int HW, int C, void* stream);
 
+/* Device-side input transform of a minibatch (utils.py:84-88: Resize((224,224)) -> RandomHorizontalFlip ->
+ * RandomVerticalFlip -> ToTensor -> Normalize, applied per image at utils.py:45-47 and stacked at utils.py:68).
+ * Resize is Pillow's 8-bit BILINEAR resample, bit for bit (horizontal pass, uint8 intermediate, vertical pass);
+ * the coin flips are the caller's; `lut` = the caller's float32 table ((v / 255) - mean[c]) / std[c].
+ * Limits: out_h, out_w <= 320; down-scaling factors up to 19 per axis. */
+typedef struct st_image_batch_desc {
+  const uint8_t* src;      /* device: the batch's RGB images, HWC uint8, back to back */
+  int64_t src_bytes;       /* size of src (offset[b] + 3 * height[b] * width[b] <= src_bytes for every b) */
+  const int64_t* offset;   /* device [batch]: byte offset of image b in src */
+  const int32_t* height;   /* device [batch] */
+  const int32_t* width;    /* device [batch] */
+  const int32_t* flip;     /* device [batch]: bit 0 = left-right, bit 1 = top-bottom; NULL = no flips */
+  int batch;
+  int max_height, max_width; /* bounds of height[] / width[] (sizes the launch and the scratch) */
+  int out_h, out_w;
+  const float* lut;        /* device [3][256] */
+  uint8_t* tmp;            /* device scratch, batch * max_height * out_w * 3 bytes */
+  float* out;              /* device (batch, 3, out_h, out_w) fp32: the `images` tensor of utils.py:68 */
+  uint8_t* out_u8;         /* optional device (batch, out_h, out_w, 3): the resized + flipped pixels before ToTensor */
+} st_image_batch_desc;
+int st_image_transform(const st_image_batch_desc* d, void* stream);
+
 /* Generic helpers */
 int st_cast(const void* x, void* y, int from_dtype, int to_dtype, long n, void* stream);
 /* y[c][r] = x[r][c]; y has leading dimension ldy >= rows, pad columns zero-filled */

@@ -61,8 +61,15 @@ class PackedSeq(C.Structure):
                 ("rows_b", c_p), ("rows_t", c_p), ("prev_row", c_p), ("caption", c_p)]
 
 
+class ImageBatchDesc(C.Structure):
+    _fields_ = [("src", c_p), ("src_bytes", C.c_int64), ("offset", c_p), ("height", c_p), ("width", c_p), ("flip", c_p), ("batch", c_i),
+                ("max_height", c_i), ("max_width", c_i), ("out_h", c_i), ("out_w", c_i), ("lut", c_p), ("tmp", c_p),
+                ("out", c_p), ("out_u8", c_p)]
+
+
 _SIGS = {
     "st_version": ([], c_i),
+    "st_image_transform": ([C.POINTER(ImageBatchDesc), c_p], c_i),
     "st_conv": ([C.POINTER(ConvDesc), c_p], c_i),
     "st_conv_batch": ([C.POINTER(ConvDesc), c_i, c_p], c_i),
     "st_tune": ([c_i, c_i, c_i], c_i),
