@@ -151,8 +151,47 @@ def gen_bleu(ref, name):
     print(name, score)
 
 
+def gen_eval(ref, name):
+    """Inputs + outputs of the reference's evaluate() (evaluation_metrics.py:662) and of its three scorers."""
+    rng = np.random.RandomState(5)
+    words = ["a", "man", "dog", "on", "the", "beach", "with", "red", "ball", "sits", "runs", "cat", "two", "<unk>"]
+    cases = {}
+    for case, nimg in (("batch24", 24), ("single", 1), ("pair", 2)):
+        target, predicted = [], []
+        for i in range(nimg):
+            refs = [[str(w) for w in rng.choice(words, size=rng.randint(3, 12))] for _ in range(rng.randint(1, 5))]
+            hyp = list(refs[rng.randint(len(refs))])
+            for j in range(len(hyp)):
+                if rng.rand() < 0.35:
+                    hyp[j] = str(rng.choice(words))
+            if rng.rand() < 0.4:
+                hyp = hyp[:rng.randint(1, len(hyp) + 1)]
+            if rng.rand() < 0.2:
+                hyp = hyp + [str(w) for w in rng.choice(words, size=rng.randint(1, 6))]
+            if case == "batch24" and i == 7:
+                hyp = []                                   # a caption that starts with <end>
+            if case == "batch24" and i == 11:
+                hyp = list(refs[0])                        # exact copy of a reference
+            target.append(refs)
+            predicted.append(hyp)
+        scores = ref.metrics.evaluate(target, predicted)
+        gts = {i: [" ".join(s) for s in target[i]] for i in range(nimg)}
+        res = {i: [" ".join(predicted[i])] for i in range(nimg)}
+        _, bleu_img = ref.metrics.Bleu(4).compute_score(gts, res)
+        _, cider_img = ref.metrics.Cider().compute_score(gts, res)
+        _, rouge_img = ref.metrics.Rouge().compute_score(gts, res)
+        cases[case] = {"target": target, "predicted": predicted, "scores": {k: float(v) for k, v in scores.items()},
+                       "bleu_per_image": [list(map(float, b)) for b in bleu_img],
+                       "cider_per_image": list(map(float, cider_img)), "rouge_per_image": list(map(float, rouge_img))}
+        print(name, case, scores)
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(cases, f)
+
+
 def main():
     assert _refload.available(), "reference not present"
+    if sys.argv[1:] == ["eval"]:
+        return gen_eval(_refload.load_reference(), "eval_small.json")
     os.makedirs(OUT, exist_ok=True)
     ref = _refload.load_reference()
     gen_rnn(ref, "gru", "gru_small.npz")
@@ -161,6 +200,7 @@ def main():
     gen_attn(ref, "lstm", "attn_lstm_small.npz")
     gen_beam(ref, "beam_small.npz")
     gen_bleu(ref, "bleu_small.json")
+    gen_eval(ref, "eval_small.json")
 
 
 if __name__ == "__main__":
