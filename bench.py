@@ -135,7 +135,7 @@ def main():
     # steps (the first one unpipelined, the second half-pipelined).
     pipe = not a.no_pipeline
     def ahead(k, n):   # the minibatches after step k that exist inside this loop (never across a timing boundary)
-        return dict(upcoming=[image] * min(3, n - 1 - k) if pipe else ())
+        return dict(upcoming=[image] * min(trainer.depth, n - 1 - k) if pipe else ())
     for k in range(a.warmup):
         trainer.step(image, caption, lens, **ahead(k, a.warmup))
     trainer.flush()

@@ -17,6 +17,8 @@ each other's launch tails and pair the HBM-bound normalise passes with the MFMA-
 forward measured, tools/two_stream_encoder.py).  The arithmetic and its order per sample are unchanged -- the running
 BatchNorm buffers are updated in minibatch order (cnn.py) -- only the schedule is.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -49,7 +51,7 @@ class Trainer:
         self._pre = []        # FIFO of (images, pooled features, event): backbone forwards issued ahead on the side streams
         self._side = []
         self._rr = 0
-        self.depth = 3        # backbone forwards kept in flight ahead of the trainable part (3 streams: 5.3 ms per forward, 2: 5.6, 1: 6.8)
+        self.depth = int(os.environ.get("ST_PIPE_DEPTH", "3"))        # backbone forwards kept in flight ahead of the trainable part (B=128 step: depth 1: 6.8 ms per forward, 2: 5.6, 3: 5.3 = 5.96 ms/step; 4: 6.35 ms/step, 5: 7.46 -- more forwards in flight evict each other's activations from the 256 MB Infinity Cache)
 
     def trainable_params(cnn, rnn):
         """main.py:96: rnn.parameters() + cnn.linear_secondlast_layer + cnn.last_layer."""
