@@ -176,7 +176,7 @@ def main():
         try:
             import csv, glob
             f = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic.csv")))[-1]
-            rows = [r for r in csv.reader(open(f)) if r and r[0].startswith("igemm_kernel<bf16,128,128,2,4,")]
+            rows = [r for r in csv.reader(open(f)) if r and (r[0].startswith("igemm_kernel<bf16,128,128,2,4,") or r[0] == "igemm_s3b_kernel")]
             if v == 0 and rows:
                 traffic = round(sum(float(r[1]) * float(r[4]) for r in rows) / sum(float(r[1]) for r in rows) * 1e6)
         except Exception:
