@@ -324,11 +324,15 @@ int gemm_nt(const void* a, int lda, const void* w, int ldw, void* y, int ldy, in
 
 }  // namespace
 
+// Greedy decoding keeps one arg-max key row per step (no re-arming between steps) for up to kFusedSteps steps, so that
+// layer 0 of step t+1 can gather its embedding rows from step t's keys itself (one launch less per step).
+constexpr int kFusedSteps = 64;
+
 extern "C" size_t st_rnn_greedy_workspace_bytes(const st_rnn_params* p, int B) {
   if (!p || B <= 0) return 0;
   const size_t es = st_dtype_size(p->dtype);
   const size_t hb = al((size_t)p->L * B * p->H * es);
-  return 4 * hb + al((size_t)B * p->E * es) + al((size_t)B * up8(p->V) * sizeof(float)) + al((size_t)B * sizeof(unsigned long long));
+  return 4 * hb + al((size_t)B * p->E * es) + al((size_t)B * up8(p->V) * sizeof(float)) + al((size_t)B * kFusedSteps * sizeof(unsigned long long));
 }
 
 extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, int steps, void* workspace, size_t workspace_bytes,
@@ -348,7 +352,8 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
   char* xbuf = ws + 4 * hb;
   float* logits = reinterpret_cast<float*>(xbuf + al((size_t)B * E * es));
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(logits) + al((size_t)B * Vp * sizeof(float)));
-  if (!logits_out && hipMemsetAsync(keys, 0, (size_t)B * sizeof(unsigned long long), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
+  const bool fused = !logits_out && steps <= kFusedSteps;   // keys[t][B]; otherwise one row, re-armed by keys_to_ids_embed_kernel
+  if (!logits_out && hipMemsetAsync(keys, 0, (size_t)B * (fused ? steps : 1) * sizeof(unsigned long long), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
   const void* x = feat;
   int cur = 0;
   for (int t = 0; t < steps; ++t) {
@@ -359,6 +364,10 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
       a.M = B; a.N = H; a.gstride = H;
       a.A2 = l == 0 ? x : hbuf[nxt] + (size_t)(l - 1) * B * H * es;
       a.W2 = p->w_ih[l]; a.K2 = l == 0 ? E : H; a.lda2 = a.K2; a.ldw2 = a.K2;
+      if (l == 0 && fused && t > 0) {                   // x = embedding rows of step t-1's tokens, gathered by the cell
+        a.A2 = p->emb; a.x_keys = keys + (size_t)(t - 1) * B; a.x_V = V;
+        a.ids_out = ids_out; a.ids_stride = steps; a.ids_t = t - 1;
+      }
       a.A = t > 0 ? hbuf[cur] + (size_t)l * B * H * es : nullptr;
       a.W = p->w_hh[l]; a.K = H; a.lda = H; a.ldw = H;
       a.hprev = a.A; a.ldhp = H;
@@ -373,6 +382,7 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
     if (!logits_out) {
       // fast path: vocabulary projection with a fused running arg-max (the logits are never written)
       const char* htop = hbuf[nxt] + (size_t)(L - 1) * B * H * es;
+      unsigned long long* kt = fused ? keys + (size_t)t * B : keys;
       const int epc = dt == ST_BF16 ? 8 : 4;
       int rpp = (int)((128 * 1024) / ((size_t)H * es)) & ~15;
       if (rpp > ((B + 15) & ~15)) rpp = (B + 15) & ~15;
@@ -389,23 +399,25 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
         }
         const dim3 vgrid((V + 63) / 64, ysplit);
         if (dt == ST_BF16)
-          hipLaunchKernelGGL(vocab_argmax_lds_kernel<bf16_t>, vgrid, dim3(256), lds, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, keys, rpp);
+          hipLaunchKernelGGL(vocab_argmax_lds_kernel<bf16_t>, vgrid, dim3(256), lds, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, kt, rpp);
         else
-          hipLaunchKernelGGL(vocab_argmax_lds_kernel<float>, vgrid, dim3(256), lds, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, keys, rpp);
+          hipLaunchKernelGGL(vocab_argmax_lds_kernel<float>, vgrid, dim3(256), lds, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, kt, rpp);
       } else {
         const int nsl = (V + 127) / 128, nmt = (B + 15) / 16;
         const dim3 vgrid(((nsl + 7) / 8) * 8 * nmt);
         if (dt == ST_BF16)
-          hipLaunchKernelGGL(vocab_argmax_kernel<bf16_t>, vgrid, dim3(256), 0, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, keys);
+          hipLaunchKernelGGL(vocab_argmax_kernel<bf16_t>, vgrid, dim3(256), 0, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, kt);
         else
-          hipLaunchKernelGGL(vocab_argmax_kernel<float>, vgrid, dim3(256), 0, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, keys);
+          hipLaunchKernelGGL(vocab_argmax_kernel<float>, vgrid, dim3(256), 0, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, kt);
       }
       ST_LAUNCH_CHECK();
-      if (dt == ST_BF16)
-        hipLaunchKernelGGL(keys_to_ids_embed_kernel<bf16_t>, dim3(B), dim3(64), 0, st, keys, ids_out, steps, t, (const bf16_t*)p->emb, (bf16_t*)xbuf, E, V);
-      else
-        hipLaunchKernelGGL(keys_to_ids_embed_kernel<float>, dim3(B), dim3(64), 0, st, keys, ids_out, steps, t, (const float*)p->emb, (float*)xbuf, E, V);
-      ST_LAUNCH_CHECK();
+      if (!fused || t == steps - 1) {                   // fused: only the last step's ids are left to write
+        if (dt == ST_BF16)
+          hipLaunchKernelGGL(keys_to_ids_embed_kernel<bf16_t>, dim3(B), dim3(64), 0, st, kt, ids_out, steps, t, (const bf16_t*)p->emb, (bf16_t*)xbuf, E, V);
+        else
+          hipLaunchKernelGGL(keys_to_ids_embed_kernel<float>, dim3(B), dim3(64), 0, st, kt, ids_out, steps, t, (const float*)p->emb, (float*)xbuf, E, V);
+        ST_LAUNCH_CHECK();
+      }
       x = xbuf;
       cur = nxt;
       continue;

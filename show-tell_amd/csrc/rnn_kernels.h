@@ -16,6 +16,10 @@ struct RnnGemmArgs {
   void* hout2; int ldho2;              // optional second copy of h' (decode: running state + layer output)
   void* cache; int ldcache;            // saved gates for BPTT (NULL at inference)
   unsigned long long* argmax_keys;     // EPI 3: per-row packed (value, index) maxima
+  // greedy decode, layer 0: row m of the x operand is A2 + token(x_keys[m]) * lda2 (A2 = the embedding table), i.e. the
+  // embedding gather of the previous step's arg-max happens inside the cell; block column 0 also writes the token ids
+  const unsigned long long* x_keys; int x_V;
+  long* ids_out; int ids_stride, ids_t;
 };
 
 // Up to kRnnBatch independent cells in ONE launch (blockIdx.z picks the cell): the (layer, time) wavefront of the

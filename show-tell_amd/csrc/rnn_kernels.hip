@@ -84,7 +84,17 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int mbase, int 
     const int m = mbase + t * 16 + r16;
     mok[t] = m < a.M;
     AH[t] = reinterpret_cast<const T*>(a.A) + (long)m * a.lda;
-    AX[t] = reinterpret_cast<const T*>(a.A2) + (long)m * a.lda2;
+    long xrow = m;
+    if (HAS_X && a.x_keys) {                           // token of the previous step -> embedding row
+      int tok = 0;
+      if (mok[t]) {
+        tok = (int)(0xffffffffu - (unsigned)(a.x_keys[m] & 0xffffffffull));
+        if (tok < 0 || tok >= a.x_V) tok = 0;
+        if (a.ids_out && n0 == 0 && kslice == 0 && q4 == 0) a.ids_out[(long)m * a.ids_stride + a.ids_t] = tok;
+      }
+      xrow = tok;
+    }
+    AX[t] = reinterpret_cast<const T*>(a.A2) + xrow * a.lda2;
   }
   const int nsH = hasH ? (a.K + 4 * EPC - 1) / (4 * EPC) : 0, nsX = hasX ? (a.K2 + 4 * EPC - 1) / (4 * EPC) : 0;
   const int spwH = (nsH + 3) / 4, spwX = (nsX + 3) / 4;
