@@ -286,6 +286,35 @@ def main():
                 del cnn_a, rnn_a, opt_a
             except Exception as e:
                 secondary["attention_error"] = repr(e)
+            # input pipeline (utils.py:84-88 on the GPU, data.py): 128 COCO-shaped uint8 images -> (128, 3, 224, 224) fp32
+            try:
+                import numpy as np
+                from showtell_amd.data import DeviceTransform
+                rng = np.random.default_rng(0)
+                shapes = [(480, 640), (640, 480), (427, 640), (375, 500)]
+                imgs = [rng.integers(0, 256, size=shapes[i % 4] + (3,), dtype=np.uint8) for i in range(B)]
+                tfm = DeviceTransform()
+                for _ in range(2):
+                    tfm(imgs)
+                torch.cuda.synchronize()
+                tt = time.perf_counter()
+                for _ in range(5):
+                    tfm(imgs)
+                torch.cuda.synchronize()
+                tt = (time.perf_counter() - tt) / 5
+                secondary["input_transform_host_arrays_images_per_sec"] = round(B / tt, 0)      # staging pass + PCIe + 2 kernels
+                flat = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).pin_memory()
+                hs, ws = [im.shape[0] for im in imgs], [im.shape[1] for im in imgs]
+                for _ in range(2):
+                    tfm.packed(flat, hs, ws)
+                torch.cuda.synchronize()
+                tt = time.perf_counter()
+                for _ in range(5):
+                    tfm.packed(flat, hs, ws)
+                torch.cuda.synchronize()
+                secondary["input_transform_pinned_buffer_images_per_sec"] = round(B * 5 / (time.perf_counter() - tt), 0)   # PCIe + 2 kernels
+            except Exception as e:
+                secondary["input_transform_error"] = repr(e)
         except Exception as e:
             secondary = {"error": repr(e)}
     if world > 1:

@@ -57,27 +57,41 @@ class DeviceTransform:
             if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3 or a.shape[0] < 1 or a.shape[1] < 1:
                 raise ValueError("DeviceTransform expects HWC uint8 RGB images, got %s %s" % (a.dtype, a.shape))
             arrs.append(np.ascontiguousarray(a))
-        B = len(arrs)
-        if B == 0:
+        if not arrs:
             raise ValueError("DeviceTransform: empty batch")
+        host = torch.empty(sum(a.size for a in arrs), dtype=torch.uint8, pin_memory=True)
+        hv, o = host.numpy(), 0
+        for a in arrs:
+            hv[o:o + a.size] = a.reshape(-1)
+            o += a.size
+        return self.packed(host, [a.shape[0] for a in arrs], [a.shape[1] for a in arrs], hflip, vflip, return_u8)
+
+    def packed(self, pixels, heights, widths, hflip=None, vflip=None, return_u8=False):
+        """The same for pixels that are already back to back in ONE uint8 tensor (image b = ``heights[b] * widths[b] * 3``
+        bytes, HWC): a pinned host buffer that the decode workers filled in place (one asynchronous copy, no staging pass
+        on this thread) or a CUDA tensor."""
+        if not torch.cuda.is_available():
+            raise _lib.ShowTellHipError("DeviceTransform needs the GPU (the HIP path has no CPU fallback)")
+        B = len(heights)
+        if B == 0 or len(widths) != B:
+            raise ValueError("DeviceTransform: empty batch or heights / widths mismatch")
         if hflip is None:
             coins = [(random.random() < self.hflip_p, random.random() < self.vflip_p) for _ in range(B)]
             hflip, vflip = [c[0] for c in coins], [c[1] for c in coins]
         elif vflip is None:
             vflip = [False] * B
-        sizes = np.asarray([a.size for a in arrs], np.int64)
-        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
         meta = np.empty((3, B), np.int32)
-        meta[0] = [a.shape[0] for a in arrs]
-        meta[1] = [a.shape[1] for a in arrs]
+        meta[0], meta[1] = heights, widths
         meta[2] = [int(bool(h)) | (int(bool(v)) << 1) for h, v in zip(hflip, vflip)]
-        host = torch.empty(int(sizes.sum()), dtype=torch.uint8, pin_memory=True)
-        hv = host.numpy()
-        for a, o in zip(arrs, offs):
-            hv[o:o + a.size] = a.reshape(-1)
+        if meta[0].min() < 1 or meta[1].min() < 1:
+            raise ValueError("DeviceTransform: empty image")
+        sizes = meta[0].astype(np.int64) * meta[1] * 3
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        if pixels.dtype != torch.uint8 or pixels.dim() != 1 or pixels.numel() < int(sizes.sum()):
+            raise ValueError("DeviceTransform: pixels must be a 1-D uint8 tensor holding all %d bytes" % int(sizes.sum()))
         dev = self.device
         with torch.cuda.device(dev):
-            src = host.to(dev, non_blocking=True)
+            src = pixels.to(dev, non_blocking=True)
             d_off = torch.from_numpy(offs).pin_memory().to(dev, non_blocking=True)
             d_meta = torch.from_numpy(meta).pin_memory().to(dev, non_blocking=True)
             if self._lut is None or self._lut.device != src.device:

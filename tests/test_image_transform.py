@@ -104,6 +104,22 @@ def test_device_transform_full_batch_feeds_the_encoder():
 
 
 @pytest.mark.gpu
+def test_device_transform_packed_buffer_equals_list_path():
+    from showtell_amd.data import DeviceTransform
+    shapes = [(120, 90), (64, 333), (224, 224), (300, 200)]
+    imgs = [O.synthetic_image(h, w, 80 + i) for i, (h, w) in enumerate(shapes)]
+    hf, vf = [True, False, False, True], [False, False, True, True]
+    tf = DeviceTransform()
+    want = tf(imgs, hflip=hf, vflip=vf)
+    flat = torch.from_numpy(np.concatenate([a.reshape(-1) for a in imgs]))
+    hs, ws = [s_[0] for s_ in shapes], [s_[1] for s_ in shapes]
+    for buf in (flat.pin_memory(), flat.cuda()):
+        assert torch.equal(tf.packed(buf, hs, ws, hf, vf), want)
+    with pytest.raises(ValueError):
+        tf.packed(flat[:-1].cuda(), hs, ws, hf, vf)
+
+
+@pytest.mark.gpu
 def test_device_transform_errors():
     from showtell_amd import ShowTellHipError
     from showtell_amd.data import DeviceTransform
