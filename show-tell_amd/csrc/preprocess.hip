@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(256) resize_h_kernel(st_image_batch_desc d, in
   const int b = blockIdx.y;
   const int H = d.height[b], W = d.width[b];
   const int y0 = blockIdx.x * kRowsH;
-  if (y0 >= H || H > d.max_height || W > d.max_width) return;   // sizes beyond the declared bounds: nothing is touched
+  // sizes beyond the declared bounds, or an image that does not lie inside src: nothing is touched
+  if (y0 >= H || H > d.max_height || W > d.max_width || d.offset[b] < 0 || d.offset[b] + (int64_t)H * W * 3 > d.src_bytes) return;
   for (int o = threadIdx.x; o < ow; o += 256) count[o] = tap_coeffs(W, ow, o, kc + o, ow, taps, first + o);
   __syncthreads();
   const uint8_t* src = d.src + d.offset[b];
