@@ -60,9 +60,10 @@ __device__ __forceinline__ int clip8(int acc) {
 }
 
 // tmp[b][y][xo][c] = horizontal resample of row y of image b.  grid (ceil(max_h / kRowsH), B), 256 threads.
-// Dynamic LDS: tap table [taps][ow], first[ow], count[ow].  A tap's three channel bytes come from ONE unaligned
-// dword load (the pass is bound by vector-memory instruction issue: three byte loads per tap ran 2x slower, and
-// staging the rows in LDS and reading bytes there slower still); the last bytes of the buffer fall back to byte loads.
+// Dynamic LDS: tap table [taps][ow], first[ow], count[ow].  Two taps' channel bytes come from ONE unaligned 8-byte
+// load and four pixels of the intermediate leave as three aligned dwords; the pass is bound by its integer VALU work
+// (three byte loads per tap ran 1.4x slower, staging the rows in LDS and reading bytes there slower still); the last
+// bytes of the buffer fall back to byte loads.
 __global__ void __launch_bounds__(256) resize_h_kernel(st_image_batch_desc d, int taps) {
   extern __shared__ int smem[];
   const int ow = d.out_w;
@@ -80,14 +81,24 @@ __global__ void __launch_bounds__(256) resize_h_kernel(st_image_batch_desc d, in
   const uint8_t* src_end = d.src + d.src_bytes;
   uint8_t* tmp = d.tmp + (size_t)b * d.max_height * ow * 3;
   const int rows = min(kRowsH, H - y0);
+  const bool packed = (ow & 3) == 0 && (reinterpret_cast<uintptr_t>(d.tmp) & 3) == 0;
   for (int idx = threadIdx.x; idx < rows * ow; idx += 256) {
     const int r = idx / ow, o = idx - r * ow;
     const int y = y0 + r;
     const uint8_t* p = src + ((size_t)y * W + first[o]) * 3;
     int a0 = 1 << (kPrecisionBits - 1), a1 = a0, a2 = a0;
     const int n = count[o];
-    if (p + 3 * n + 1 <= src_end) {                              // every tap's dword lies inside the buffer
-      for (int x = 0; x < n; ++x) {
+    if (p + 3 * n + 2 <= src_end) {                              // every load below lies inside the buffer
+      int x = 0;
+      for (; x + 1 < n; x += 2) {                                // two taps = 6 bytes from one unaligned 8-byte load
+        const int k0 = kc[x * ow + o], k1 = kc[(x + 1) * ow + o];
+        uint32_t v[2];
+        __builtin_memcpy(v, p + x * 3, 8);
+        a0 += (int)(v[0] & 255u) * k0 + (int)(v[0] >> 24) * k1;
+        a1 += (int)((v[0] >> 8) & 255u) * k0 + (int)(v[1] & 255u) * k1;
+        a2 += (int)((v[0] >> 16) & 255u) * k0 + (int)((v[1] >> 8) & 255u) * k1;
+      }
+      if (x < n) {
         const int k = kc[x * ow + o];
         uint32_t v;
         __builtin_memcpy(&v, p + x * 3, 4);
@@ -103,10 +114,19 @@ __global__ void __launch_bounds__(256) resize_h_kernel(st_image_batch_desc d, in
         a2 += (int)p[x * 3 + 2] * k;
       }
     }
+    const uint32_t px = (uint32_t)clip8(a0) | ((uint32_t)clip8(a1) << 8) | ((uint32_t)clip8(a2) << 16);
     uint8_t* q = tmp + ((size_t)y * ow + o) * 3;
-    q[0] = (uint8_t)clip8(a0);
-    q[1] = (uint8_t)clip8(a1);
-    q[2] = (uint8_t)clip8(a2);
+    if (packed) {
+      // four neighbouring pixels = 12 bytes = three aligned dwords, written by three of the four lanes (three byte
+      // stores per pixel were 41 M partial-dword writes per batch); ow % 4 == 0 keeps a quad inside one row and one loop trip
+      const uint32_t nx = __shfl_down(px, 1, 64);
+      const int j = o & 3;
+      if (j < 3) *reinterpret_cast<uint32_t*>(q + j) = (px >> (8 * j)) | (nx << (24 - 8 * j));
+    } else {
+      q[0] = (uint8_t)px;
+      q[1] = (uint8_t)(px >> 8);
+      q[2] = (uint8_t)(px >> 16);
+    }
   }
 }
 
