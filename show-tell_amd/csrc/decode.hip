@@ -5,6 +5,7 @@
 // kernel, gates in its epilogue), one MFMA GEMM for the vocabulary projection and one
 // arg-max + embedding-gather kernel.  Everything is issued from this one C call.
 #include "common.h"
+#include <stdlib.h>
 #include "rnn_kernels.h"
 #include <string.h>
 
@@ -122,6 +123,85 @@ __global__ __launch_bounds__(256) void softmax_topk_kernel(const float* __restri
       top_p[(long)row * k + j] = raw ? best : expf(best - M) / S;
     }
     __syncthreads();
+  }
+}
+
+
+// The same result for k <= 8 in TWO passes over the row instead of 2 + k: pass 1 keeps, per thread, the maximum and a sorted
+// list of its k best (value descending, index ascending: a thread meets its indices in increasing order, so strict '>' on
+// insertion keeps first-index-wins); pass 2 is the sum of exponentials in exactly the order of softmax_topk_kernel (the
+// probabilities are bit-identical); then k rounds of a block-wide arg-max over the threads' list heads pick the winners.
+template <int KMAX>
+__global__ __launch_bounds__(256) void softmax_topk_fast_kernel(const float* __restrict__ logits, int ldl, int V, int k,
+                                                                float* __restrict__ top_p, long* __restrict__ top_id, int raw) {
+  __shared__ float sv[4]; __shared__ int si[4]; __shared__ float ssum[4];
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float* l = logits + (long)row * ldl;
+  float lv[KMAX]; int li[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q) { lv[q] = -INFINITY; li[q] = 0x7fffffff; }
+  float M = -INFINITY;
+  constexpr int UN = 8;                                      // loads in flight per thread: the passes are L2-latency bound
+  for (int i0 = threadIdx.x; i0 < V; i0 += UN * 256) {
+    float vv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) vv[u] = i0 + u * 256 < V ? l[i0 + u * 256] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * 256;
+      const float v = vv[u];
+      if (i >= V) continue;
+      M = fmaxf(M, v);
+      if (v > lv[KMAX - 1] || li[KMAX - 1] == 0x7fffffff) {  // enters the list (an empty slot takes anything)
+        float cv = v; int cidx = i;
+#pragma unroll
+        for (int q = 0; q < KMAX; ++q) {
+          const bool before = cv > lv[q] || (li[q] == 0x7fffffff && cidx != 0x7fffffff);
+          if (before) { const float tv = lv[q]; const int ti = li[q]; lv[q] = cv; li[q] = cidx; cv = tv; cidx = ti; }
+        }
+      }
+    }
+  }
+  M = wave_max(M);
+  if (lane == 0) sv[wid] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+  float S = 0.f;
+  if (!raw) {
+    for (int i0 = threadIdx.x; i0 < V; i0 += UN * 256) {     // same order of additions as softmax_topk_kernel
+      float vv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) vv[u] = i0 + u * 256 < V ? l[i0 + u * 256] : 0.f;
+#pragma unroll
+      for (int u = 0; u < UN; ++u) if (i0 + u * 256 < V) S += expf(vv[u] - M);
+    }
+    S = wave_sum(S);
+    if (lane == 0) ssum[wid] = S;
+  }
+  __syncthreads();
+  if (!raw) S = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+  for (int j = 0; j < k; ++j) {
+    float best = lv[0]; int bi = li[0];                      // this thread's best remaining candidate
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    best = sv[0]; bi = si[0];
+    for (int w = 1; w < 4; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    if (li[0] == bi && bi != 0x7fffffff) {                   // the winner's owner moves on to its next candidate
+#pragma unroll
+      for (int q = 0; q + 1 < KMAX; ++q) { lv[q] = lv[q + 1]; li[q] = li[q + 1]; }
+      lv[KMAX - 1] = -INFINITY; li[KMAX - 1] = 0x7fffffff;
+    }
+    if (bi >= V) bi = 0;
+    if (threadIdx.x == 0) {
+      top_id[(long)row * k + j] = bi;
+      top_p[(long)row * k + j] = raw ? best : expf(best - M) / S;
+    }
   }
 }
 
@@ -465,7 +545,14 @@ extern "C" int st_softmax_topk(const float* logits, int ldl, int n, int V, int k
   ST_CHECK(logits && top_p && top_id, "st_softmax_topk: null pointer");
   ST_CHECK(k >= 1 && k <= 32 && k <= V && ldl >= V, "st_softmax_topk: need 1 <= k <= min(32, V)");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(softmax_topk_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
+  // k <= 8 (every beam width in use): two passes over the row; the 2 + k pass form stays as the general case and as the
+  // cross-check (ST_TOPK_SLOW=1)
+  static int slow = -1;
+  if (slow < 0) { const char* e = getenv("ST_TOPK_SLOW"); slow = e ? atoi(e) : 0; }
+  if (k <= 8 && !slow && (long)k * 256 <= V)
+    hipLaunchKernelGGL(softmax_topk_fast_kernel<8>, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
+  else
+    hipLaunchKernelGGL(softmax_topk_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
   ST_LAUNCH_CHECK();
   return 0;
 }

@@ -520,7 +520,8 @@ int rnn_gemm_launch_batch(const RnnGemmArgs* cells, int ncells, int dtype, int e
   if (nc == 0) return 0;
   const dim3 grid((maxN + 15) / 16, (maxM + 15) / 16, nc), block(256);
   // many cells in one launch: the weights are most of the L2 traffic -> two row tiles per block share them
-  const bool mt2 = nc >= 2 && maxM > 16 && epi != 3;
+  // ... and so do the 16-row tiles of one tall cell (beam search steps 1280 rows at a time: 80 row tiles re-read the weights)
+  const bool mt2 = (nc >= 2 || maxM >= 512) && maxM > 16 && epi != 3;
   const dim3 grid2((maxN + 15) / 16, (maxM + 31) / 32, nc);
 #define RG(T, NG, EPI, HX) do { if (mt2) hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX, 2>), grid2, block, 0, st, b); \
                                else hipLaunchKernelGGL((rnn_gemm_kernel<T, NG, EPI, HX, 1>), grid, block, 0, st, b); } while (0)
