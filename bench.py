@@ -187,6 +187,30 @@ def main():
                 "avg_launch_us": round(ms[v] * 1e3 / max(1, n[v]), 2),
                 "all_igemm_TFLOPs": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                 "all_igemm_ms_per_step": round(tot_ms / max(1, a.profile_steps), 3)}
+    # ---- per-phase split of one plain (unpipelined) step, SURVEY 8(d) config 2: HIP events on the launch stream ----------
+    phases = None
+    if rank == 0 and world == 1:
+        try:
+            from showtell_amd.head import linear_bn1d
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(3)]
+            for e in ev:
+                e[0].record()
+                pooled = cnn.backbone_features(image)                                    # frozen encoder (cnn.py:46-47)
+                e[1].record()
+                opt.zero_grad()
+                feat_ = linear_bn1d(pooled, cnn.linear_secondlast_layer, cnn.last_layer, cnn.training, cnn.compute_dtype)
+                ls = rnn.loss(feat_, caption, lens)                                      # head + decoder forward + loss
+                e[2].record()
+                ls.backward()
+                e[3].record()
+                opt.step()
+                e[4].record()
+            torch.cuda.synchronize()
+            names_ = ["encoder_forward", "head_decoder_forward_loss", "backward", "optimizer"]
+            phases = {nm: round(sum(e[i].elapsed_time(e[i + 1]) for e in ev[1:]) / 2, 3) for i, nm in enumerate(names_)}
+            phases["unit"] = "ms per plain step (no forwards in flight); the pipelined step overlaps the encoder of later minibatches with the rest"
+        except Exception as e:
+            phases = {"error": repr(e)}
     # ---- secondary (rank 0, N=1): greedy decode step against the HBM roofline, beam=5 captions/sec -------------
     secondary = None
     if rank == 0 and world == 1:
@@ -334,7 +358,7 @@ def main():
                           "schedule": ("frozen-backbone forwards of the next 3 minibatches in flight on side streams (train.py); "
                                        "every step's full work is inside the timed region") if pipe else "plain loop (--no-pipeline)",
                           "final_loss": round(final_loss, 4)},
-               "roofline": roof, "secondary": secondary}
+               "roofline": roof, "phases": phases, "secondary": secondary}
         if world == 1 and not a.no_cpu_baseline:
             cores = min(os.cpu_count() or 1, 16)
             try:
