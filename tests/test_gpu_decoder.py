@@ -73,6 +73,35 @@ def test_fp32_greedy_ids_exact(cell, name):
     assert np.array_equal(ids1.cpu().numpy(), d["greedy_b1"])
 
 
+@pytest.mark.parametrize("cell,name", [("gru", "gru_small.npz"), ("lstm", "lstm_small.npz")])
+def test_greedy_paths_agree(cell, name):
+    """st_rnn_greedy has three routes: keys per step with the embedding gather inside the layer-0 cell (steps <= 64), one
+    re-armed key row (steps > 64), and materialised logits.  All must emit the same tokens."""
+    import ctypes as C
+    from showtell_amd._lib import check, lib
+    from showtell_amd.rnn import _cp, _stream
+    params, _, d = load_fixture(name)
+    m = _make(cell, params, torch.float32).eval()
+    feat = torch.from_numpy(d["feat"]).cuda()
+    B = feat.shape[0]
+    ids25, lg = m.sentence_index(feat, return_logits=True)                 # logits route
+    assert np.array_equal(ids25.cpu().numpy(), d["greedy"])
+    assert np.array_equal(lg.argmax(-1).cpu().numpy(), d["greedy"])
+    prm, keep = m._c_params()
+    nbytes = lib().st_rnn_greedy_workspace_bytes(C.byref(prm), B)
+    for steps in (25, 64, 70):
+        ws = torch.empty(nbytes, device="cuda", dtype=torch.uint8)
+        ids = torch.full((B, steps), -7, device="cuda", dtype=torch.long)
+        check(lib().st_rnn_greedy(C.byref(prm), _cp(feat), B, steps, _cp(ws), nbytes, _cp(ids), None, _stream()), "st_rnn_greedy")
+        got = ids.cpu().numpy()
+        assert np.array_equal(got[:, :25], d["greedy"]), steps
+        assert (got >= 0).all()
+        if steps == 64:
+            first64 = got
+        if steps == 70:
+            assert np.array_equal(got[:, :64], first64)
+
+
 @pytest.mark.parametrize("cell", ["gru", "lstm"])
 def test_bf16_forward_backward_close_to_oracle(cell):
     E, H, V, L, B = 64, 64, 200, 3, 16
