@@ -83,3 +83,29 @@ def test_bf16_greedy_bleu4_vs_fp32_oracle():
     gts = {str(b): [" ".join(map(str, g_ref[b].tolist()))] for b in range(8)}
     res = {str(b): [" ".join(map(str, g_hip[b].tolist()))] for b in range(8)}
     assert R.bleu_corpus(gts, res, 4)[3] >= 0.9
+
+
+@pytest.mark.parametrize("k", [1, 5, 8, 12])
+def test_softmax_topk_kernels_against_torch(k):
+    """st_softmax_topk: the two-pass form (k <= 8) and the general form (k = 12) against torch -- indices exact including
+    ties (first index wins, as torch.sort(stable) on the negated row), probabilities to float32 rounding; raw mode returns logits."""
+    import ctypes as C
+    from showtell_amd._lib import check, lib
+    from showtell_amd.rnn import _cp, _stream
+    torch.manual_seed(3)
+    n, V, ldl = 37, 5003, 5008
+    x = torch.randn(n, ldl, device="cuda")
+    x[:, ::7] = x[:, 3:4]                                # many exact ties, some of them at the top
+    x[5, :V] = 0.25                                      # a constant row: indices 0 .. k-1
+    x[6, :V] = -float("inf"); x[6, 17] = 1.0             # one finite entry
+    for raw in (0, 1):
+        p = torch.empty(n, k, device="cuda")
+        i = torch.empty(n, k, device="cuda", dtype=torch.long)
+        check(lib().st_softmax_topk(_cp(x), ldl, n, V, k, _cp(p), _cp(i), raw, _stream()), "st_softmax_topk")
+        row = x[:, :V]
+        order = torch.sort(-row, dim=1, stable=True).indices[:, :k]
+        keep = torch.ones(n, dtype=torch.bool); keep[6] = False      # row 6: only the first index is defined by a finite value
+        assert torch.equal(i[keep.cuda()], order[keep.cuda()])
+        assert int(i[6, 0]) == 17
+        ref = torch.gather(row if raw else torch.softmax(row, 1), 1, order)
+        assert torch.allclose(p[keep.cuda()], ref[keep.cuda()], rtol=2e-6, atol=1e-9)
