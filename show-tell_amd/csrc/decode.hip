@@ -549,7 +549,9 @@ extern "C" int st_softmax_topk(const float* logits, int ldl, int n, int V, int k
   // cross-check (ST_TOPK_SLOW=1)
   static int slow = -1;
   if (slow < 0) { const char* e = getenv("ST_TOPK_SLOW"); slow = e ? atoi(e) : 0; }
-  if (k <= 8 && !slow && (long)k * 256 <= V)
+  if (k <= 5 && !slow && (long)k * 256 <= V)
+    hipLaunchKernelGGL(softmax_topk_fast_kernel<5>, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
+  else if (k <= 8 && !slow && (long)k * 256 <= V)
     hipLaunchKernelGGL(softmax_topk_fast_kernel<8>, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
   else
     hipLaunchKernelGGL(softmax_topk_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
