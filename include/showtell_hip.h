@@ -304,6 +304,13 @@ int st_rnn_step(const st_rnn_params* p, const void* x, int n, const void* h_in, 
 int st_embedding_rows(const void* emb, const long* ids, void* out, int n, int E, int V, int ldo, int dtype, void* stream);
 int st_gather_state(const void* src, const int* idx, void* dst, int L, int n_src, int n_dst, int H, int dtype, void* stream);
 int st_softmax_topk(const float* logits, int ldl, int n, int V, int k, float* top_p, long* top_id, int raw, void* stream);
+/* One iteration of beam_search.py:69-94 for B images on the device: fringe slots (b, w), w < W, hold (tok, cost) with cost = +inf
+ * for an empty slot; top_p/top_id are st_softmax_topk's rows of the B*W slots (k entries, descending).  Writes the new fringe
+ * (stable W-best of the node-major, ascending-probability candidate list by float32 cumulative -log p), every new node's parent
+ * slot (-1: empty), ended[b][w] = old slot held <end> (to be harvested), gather[b*W+w] = state row of the parent, and updates
+ * done[b] (no live node left).  Needs k <= W and W * k <= 64. */
+int st_beam_select(const long* tok, const float* cost, uint8_t* done, const float* top_p, const long* top_id, int B, int W, int k,
+                   long end_id, long* new_tok, float* new_cost, int* parent, uint8_t* ended, int* gather, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Soft-attention decoder (Attention/rnn_attn.py, rnn_attn_LSTM.py; train step Attention/main_attn.py:123-134).

@@ -102,6 +102,7 @@ _SIGS = {
     "st_embedding_rows": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_gather_state": ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_softmax_topk": ([c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p], c_i),
+    "st_beam_select": ([c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_p, c_p, c_p, c_p, c_p, c_p], c_i),
     "st_attn_workspace_bytes": ([c_p, c_p], C.c_size_t),
     "st_attn_forward": ([c_p, c_p, c_p, c_p, c_p, C.c_size_t, c_p, c_i, c_i, c_p, c_i, c_p], c_i),
     "st_attn_backward": ([c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_p, C.c_size_t, c_p], c_i),

@@ -104,7 +104,62 @@ def quirky_beam(rnn, cnn_feature, beam_size, steps=CAP_MAX):
         return torch.tensor(old_sent[0], dtype=torch.long, device=cnn_feature.device)   # rnn.py:106-108
 
 
-def beam_search(rnn, cnn_feature, beam_width=4, num_hypotheses=1, max_length=50, start_id=1, end_id=2):
+def beam_search(rnn, cnn_feature, beam_width=4, num_hypotheses=1, max_length=50, start_id=1, end_id=2, on_device=True):
+    """beam_search.py:45-97 for every image of the batch; see ``beam_search_host`` for the contract.  With ``on_device`` (and
+    beam_width**2 <= 64) the fringe selection of every iteration also runs on the GPU (``st_beam_select``) over fixed
+    (image, slot) rows, so the whole search needs ONE host round trip instead of three per iteration; the Node bookkeeping
+    (harvest order, stable sort of the hypotheses, parent back-tracking) is replayed on the host from the recorded fringes.
+    The only arithmetic that differs from the host path is -log p: a correctly rounded float32 logarithm on the device, NumPy's
+    float32 log on the host (<= 1 ulp apart; the golden sequences are reproduced by both)."""
+    k = min(beam_width, rnn.vocab_size)
+    if not on_device or beam_width * k > 64:
+        return beam_search_host(rnn, cnn_feature, beam_width, num_hypotheses, max_length, start_id, end_id)
+    with torch.no_grad():
+        st = _Stepper(rnn)
+        dev = st.dev
+        B, W = cnn_feature.shape[0], beam_width
+        n = B * W
+        _, state = st.step(_feat(rnn, cnn_feature), None, want_logits=False)      # state after the image-feature step (rnn.py:41,49)
+        state = st.gather(state, torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(W))   # slot (b, w) <- image b
+        tok = torch.zeros(B, W, device=dev, dtype=torch.long); tok[:, 0] = start_id    # beam_search.py:66
+        cost = torch.full((B, W), float("inf"), device=dev, dtype=torch.float32); cost[:, 0] = 0.0
+        done = torch.zeros(B, device=dev, dtype=torch.uint8)
+        rec_tok = torch.zeros(max_length + 1, B, W, device=dev, dtype=torch.long)
+        rec_cost = torch.full((max_length + 1, B, W), float("inf"), device=dev, dtype=torch.float32)
+        rec_par = torch.full((max_length + 1, B, W), -1, device=dev, dtype=torch.int32)
+        rec_end = torch.zeros(max_length, B, W, device=dev, dtype=torch.uint8)
+        rec_tok[0], rec_cost[0] = tok, cost
+        gidx = torch.empty(n, device=dev, dtype=torch.int32)
+        tp = torch.empty(n, k, device=dev, dtype=torch.float32)
+        ti = torch.empty(n, k, device=dev, dtype=torch.long)
+        for t in range(max_length):                                                   # beam_search.py:69
+            x = st.embed(tok.view(-1))
+            logits, new_state = st.step(x, state)
+            check(lib().st_softmax_topk(_cp(logits), st.Vp, n, st.V, k, _cp(tp), _cp(ti), 0, _stream()), "st_softmax_topk")
+            ntok, ncost = rec_tok[t + 1], rec_cost[t + 1]
+            check(lib().st_beam_select(_cp(tok), _cp(cost), _cp(done), _cp(tp), _cp(ti), B, W, k, end_id, _cp(ntok), _cp(ncost),
+                                       _cp(rec_par[t + 1]), _cp(rec_end[t]), _cp(gidx), _stream()), "st_beam_select")
+            state = st.gather(new_state, gidx)
+            tok, cost = ntok, ncost
+        h_tok, h_cost, h_par, h_end = rec_tok.cpu().numpy(), rec_cost.cpu().numpy(), rec_par.cpu().numpy(), rec_end.cpu().numpy()
+    out = []
+    for b in range(B):
+        hyp = []                                                                      # (iteration of the node, slot, cost) in harvest order
+        for t, w in zip(*np.nonzero(h_end[:, b])):                                    # iteration-major, slot order inside (beam_search.py:72-76)
+            hyp.append((int(t), int(w), h_cost[t, b, w]))
+        res = []
+        for t, w, c in sorted(hyp, key=lambda e: e[2])[:num_hypotheses]:              # beam_search.py:96 (stable)
+            seq = []
+            while t >= 0 and w >= 0:
+                seq.append(int(h_tok[t, b, w]))
+                w = int(h_par[t, b, w]) if t > 0 else -1
+                t -= 1
+            res.append((seq[::-1], float(c)))
+        out.append(res)
+    return out
+
+
+def beam_search_host(rnn, cnn_feature, beam_width=4, num_hypotheses=1, max_length=50, start_id=1, end_id=2):
     """beam_search.py:45-97 for every image of the batch.  Returns, per image, a list of at most
     `num_hypotheses` (token_sequence, cum_cost) pairs; the list is empty when no beam ever emitted
     `end_id` in time (the reference returns [] then).

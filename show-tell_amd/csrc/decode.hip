@@ -559,6 +559,66 @@ extern "C" int st_softmax_topk(const float* logits, int ldl, int n, int V, int k
   return 0;
 }
 
+// One iteration of beam_search.py:69-94 for every image at once, on the device (no host round trip per step).
+// A block = one image; slot (b, w) is fringe node w.  From the OLD fringe (tok, cost; cost = +inf marks an empty slot):
+//   ended = slot holds <end> and the image is not finished            (beam_search.py:72-76: harvested by the host afterwards)
+//   live  = the other occupied slots; an image without live slots is finished from now on (:78-79)
+// candidates in the reference's order -- node-major, each node's k successors in ASCENDING probability (argsort(p)[-k:]) --
+// cost = float32(cost[w] + (-log p)); the W best by a STABLE ranking (sorted(...)[:beam_width], :94) become the new fringe.
+// Outputs: new tok / cost, the parent slot of every new node, gather[b*W + w] = row of the parent's recurrent state.
+__global__ __launch_bounds__(64) void beam_select_kernel(const long* __restrict__ tok, const float* __restrict__ cost, uint8_t* __restrict__ done,
+                                                         const float* __restrict__ top_p, const long* __restrict__ top_id, int W, int k, long end_id,
+                                                         long* __restrict__ new_tok, float* __restrict__ new_cost, int* __restrict__ parent,
+                                                         uint8_t* __restrict__ ended_rec, int* __restrict__ gather) {
+  __shared__ float cc[64];
+  __shared__ int any_live;
+  const int b = blockIdx.x, c = threadIdx.x;
+  const bool was_done = done[b] != 0;
+  if (c == 0) any_live = 0;
+  __syncthreads();
+  if (c < W) {
+    const bool occupied = cost[b * W + c] < INFINITY;
+    const bool ended = occupied && tok[b * W + c] == end_id && !was_done;
+    ended_rec[b * W + c] = ended ? 1 : 0;
+    if (occupied && !ended && !was_done) any_live = 1;
+  }
+  __syncthreads();
+  const bool finished = was_done || !any_live;
+  if (c == 0) done[b] = finished ? 1 : 0;
+  float my = INFINITY;
+  const int n = W * k;
+  if (c < n && !finished) {
+    const int w = c / k, j = c - w * k;                      // successor j in ascending probability = top-k entry k-1-j
+    const float cw = cost[b * W + w];
+    if (cw < INFINITY && tok[b * W + w] != end_id)
+      my = cw + (float)(-log((double)top_p[(long)(b * W + w) * k + (k - 1 - j)]));
+  }
+  cc[c] = c < n ? my : INFINITY;
+  __syncthreads();
+  if (c < n) {
+    int rank = 0;                                            // stable: ties keep candidate order
+    for (int o = 0; o < n; ++o) rank += (cc[o] < my || (cc[o] == my && o < c)) ? 1 : 0;
+    if (rank < W) {
+      const int w = c / k, j = c - w * k;
+      const bool ok = my < INFINITY;
+      new_cost[b * W + rank] = ok ? my : INFINITY;
+      new_tok[b * W + rank] = ok ? top_id[(long)(b * W + w) * k + (k - 1 - j)] : 0;
+      parent[b * W + rank] = ok ? w : -1;
+      gather[b * W + rank] = b * W + (ok ? w : 0);
+    }
+  }
+}
+
+extern "C" int st_beam_select(const long* tok, const float* cost, uint8_t* done, const float* top_p, const long* top_id, int B, int W, int k,
+                              long end_id, long* new_tok, float* new_cost, int* parent, uint8_t* ended, int* gather, void* stream) {
+  ST_CHECK(tok && cost && done && top_p && top_id && new_tok && new_cost && parent && ended && gather, "st_beam_select: null pointer");
+  ST_CHECK(B > 0 && W >= 1 && k >= 1 && k <= W && W * k <= 64, "st_beam_select: need 1 <= k <= W and W * k <= 64 (got W=%d k=%d)", W, k);
+  hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tok, cost, done, top_p, top_id, W, k, end_id,
+                     new_tok, new_cost, parent, ended, gather);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
 // One timestep of the multi-layer cell for n independent rows (+ optional vocabulary projection).
 extern "C" int st_rnn_step(const st_rnn_params* p, const void* x, int n, const void* h_in, const void* c_in,
                            void* h_out, void* c_out, float* logits, int ldl, void* stream) {

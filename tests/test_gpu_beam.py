@@ -109,3 +109,25 @@ def test_softmax_topk_kernels_against_torch(k):
         assert int(i[6, 0]) == 17
         ref = torch.gather(row if raw else torch.softmax(row, 1), 1, order)
         assert torch.allclose(p[keep.cuda()], ref[keep.cuda()], rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("bw,nh,dtype", [(5, 3, torch.float32), (4, 1, torch.float32), (5, 1, torch.bfloat16), (8, 2, torch.float32), (9, 1, torch.float32)])
+def test_beam_search_device_selection_equals_host_bookkeeping(bw, nh, dtype):
+    """The device-side fringe selection (st_beam_select, one host round trip per search) against the host bookkeeping that
+    replays the reference's lists: same hypotheses, sequences and order; costs to float32 rounding of -log p.  bw=9 exceeds the
+    W*k <= 64 limit of the kernel and must fall back to the host path by itself."""
+    from showtell_amd.beam import beam_search, beam_search_host
+    E, H, V, L, B = 128, 128, 600, 3, 40
+    params = R.init_decoder_params(E, H, V, L, "gru", seed=9)
+    params["linear.weight"] = params["linear.weight"] * 10.0
+    params["linear.bias"][2] += 1.0
+    m = _make("gru", params, dtype).eval()
+    feat = torch.randn(B, E, generator=torch.Generator().manual_seed(9)).cuda()
+    dev = beam_search(m, feat, beam_width=bw, num_hypotheses=nh, max_length=25)
+    host = beam_search_host(m, feat, beam_width=bw, num_hypotheses=nh, max_length=25)
+    assert len(dev) == len(host) == B
+    assert sum(1 for h in host if h) >= B // 4
+    for d_, h_ in zip(dev, host):
+        assert [s for s, _ in d_] == [s for s, _ in h_]
+        for (_, cd), (_, ch) in zip(d_, h_):
+            assert abs(cd - ch) <= 1e-5 * max(1.0, abs(ch))
