@@ -6,10 +6,11 @@ Two different things exist in the reference and both are mirrored:
   recurrent state threaded through every beam, candidates ranked by the current-step raw logit only.
 * ``beam_search``  -- the textbook search of ``beam_search.py:45-97`` (cumulative -log p, <end> moves a
   node to the hypotheses, stable sort by cost), batched over images: every step is ONE set of device
-  launches over all live nodes of all images (st_embedding_rows, st_gather_state, st_rnn_step,
-  st_softmax_topk); only the k candidates per node come back to the host, where the reference's list
-  bookkeeping (``Node`` parents, stable ``sorted``) is reproduced literally, including its float32 cost
-  accumulation under NumPy 2 and the fact that nodes ending on the last iteration are never harvested.
+  launches over the nodes of all images (st_embedding_rows, st_gather_state, st_rnn_step, st_softmax_topk and,
+  by default, st_beam_select for the fringe selection, so that a search needs one host round trip in all).
+  The reference's list bookkeeping (``Node`` parents, stable ``sorted``) is reproduced literally, including its
+  float32 cost accumulation under NumPy 2 and the fact that nodes ending on the last iteration are never
+  harvested; ``beam_search_host`` keeps that bookkeeping on the host per iteration (the cross-check).
 """
 import ctypes as C
 
