@@ -333,16 +333,8 @@ __global__ __launch_bounds__(256) void vocab_argmax_lds_kernel(const T* __restri
     }
     __syncthreads();
     const int ntile = (rows + 15) / 16;
-    for (int mt = 0; mt < ntile; ++mt) {
-      const int row = mt * 16 + r16;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < KS; ++u) {
-        if (u * 4 * EPC < K) {
-          const u32x4 fa = *reinterpret_cast<const u32x4*>(lds + row * rowb + (((u * 4 + q4) ^ (row & 7)) << 4));
-          MfmaD<T>::run(fw[u], fa, acc);
-        }
-      }
+    // per row tile: (value, first index) over this wave's 16 entries -> wbest
+    auto finish = [&](const f32x4& acc, int mt) {
       float best = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -363,7 +355,41 @@ __global__ __launch_bounds__(256) void vocab_argmax_lds_kernel(const T* __restri
           u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
           key = ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi);
         }
-        wbest[wid * rows_per_pass + row] = key;
+        wbest[wid * rows_per_pass + mt * 16 + r16] = key;
+      }
+    };
+    if (K == KS * 4 * EPC) {
+      // full-depth rows (H = 512 in bf16): no per-step guard, so the 16 fragment reads of a tile are issued ahead of its
+      // MFMAs, and two row tiles run as independent accumulator chains (the guarded loop below serialises
+      // read -> wait -> MFMA sixteen times per tile: ~10 of the kernel's 13 us at B = 128, V = 10000)
+      for (int mt = 0; mt < ntile; mt += 2) {
+        const int mt1 = mt + 1 < ntile ? mt + 1 : mt;   // odd tail: the second chain repeats the first and is dropped
+        const int row0 = mt * 16 + r16, row1 = mt1 * 16 + r16;
+        const char* p0 = lds + row0 * rowb; const char* p1 = lds + row1 * rowb;
+        const int s0 = row0 & 7, s1 = row1 & 7;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+          const u32x4 fa0 = *reinterpret_cast<const u32x4*>(p0 + (((u * 4 + q4) ^ s0) << 4));
+          const u32x4 fa1 = *reinterpret_cast<const u32x4*>(p1 + (((u * 4 + q4) ^ s1) << 4));
+          MfmaD<T>::run(fw[u], fa0, acc0);
+          MfmaD<T>::run(fw[u], fa1, acc1);
+        }
+        finish(acc0, mt);
+        if (mt1 != mt) finish(acc1, mt1);
+      }
+    } else {
+      for (int mt = 0; mt < ntile; ++mt) {
+        const int row = mt * 16 + r16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+          if (u * 4 * EPC < K) {
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(lds + row * rowb + (((u * 4 + q4) ^ (row & 7)) << 4));
+            MfmaD<T>::run(fw[u], fa, acc);
+          }
+        }
+        finish(acc, mt);
       }
     }
     __syncthreads();
