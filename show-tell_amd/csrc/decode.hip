@@ -290,13 +290,20 @@ __global__ __launch_bounds__(256) void vocab_argmax_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void vocab_argmax_lds_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                                const float* __restrict__ bias, int M, int N, int K,
-                                                               unsigned long long* __restrict__ keys, int rows_per_pass) {
+                                                               unsigned long long* __restrict__ keys, int rows_per_pass, int ysplit) {
   constexpr int EPC = MfmaD<T>::EPC, KS = 16;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   unsigned long long* wbest = reinterpret_cast<unsigned long long*>(lds + (size_t)rows_per_pass * K * sizeof(T));   // [4][rows_per_pass]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r16 = lane & 15, q4 = lane >> 4;
-  const int n0 = (blockIdx.x * 4 + wid) * 16;
+  // 1-D grid in groups of 8 * ysplit blocks: block j of a group takes vocabulary slice (group * 8 + j % 8) and row part
+  // j / 8, so the ysplit blocks that read the SAME 64-entry slice of W are 8 apart = on the same XCD under round-robin
+  // placement and the slice leaves HBM once, not once per row part (PMC: 18.3 MB per launch for a 10.2 MB matrix with a
+  // (slices, ysplit) 2-D grid, whose row parts land on different XCDs).  Speed only: any placement is correct.
+  const int grp = blockIdx.x / (8 * ysplit), j = blockIdx.x - grp * 8 * ysplit;
+  const int slice = grp * 8 + (j & 7), ypart = j >> 3;
+  const int n0 = (slice * 4 + wid) * 16;
+  if (slice * 64 >= N) return;                          // padding blocks of the last group (whole block, before any barrier)
   const int nr = n0 + r16;
   const bool nok = nr < N;
   const T* Wr = W + (long)nr * ldw;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256) void vocab_argmax_lds_kernel(const T* __restri
   for (int e = 0; e < 4; ++e) bz[e] = n + e < N ? bias[n + e] : 0.f;
   const int cpr = K / EPC;                              // 16-byte chunks per row (multiple of 8: host check)
   const int rowb = K * (int)sizeof(T);
-  for (int mb = blockIdx.y * rows_per_pass; mb < M; mb += gridDim.y * rows_per_pass) {   // grid.y splits the rows when entries alone leave CUs idle
+  for (int mb = ypart * rows_per_pass; mb < M; mb += ysplit * rows_per_pass) {   // grid.y splits the rows when entries alone leave CUs idle
     const int rows = min(rows_per_pass, M - mb);
     __syncthreads();                                    // previous pass has left the buffer
     // 8 chunks per thread in flight: the staging pass is one or two L2 round trips, not one per chunk
@@ -503,11 +510,11 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_argmax_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           attr_set = true;
         }
-        const dim3 vgrid((V + 63) / 64, ysplit);
+        const dim3 vgrid(((V + 63) / 64 + 7) / 8 * 8 * ysplit);
         if (dt == ST_BF16)
-          hipLaunchKernelGGL(vocab_argmax_lds_kernel<bf16_t>, vgrid, dim3(256), lds, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, kt, rpp);
+          hipLaunchKernelGGL(vocab_argmax_lds_kernel<bf16_t>, vgrid, dim3(256), lds, st, (const bf16_t*)htop, H, (const bf16_t*)p->w_lin, H, p->b_lin, B, V, H, kt, rpp, ysplit);
         else
-          hipLaunchKernelGGL(vocab_argmax_lds_kernel<float>, vgrid, dim3(256), lds, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, kt, rpp);
+          hipLaunchKernelGGL(vocab_argmax_lds_kernel<float>, vgrid, dim3(256), lds, st, (const float*)htop, H, (const float*)p->w_lin, H, p->b_lin, B, V, H, kt, rpp, ysplit);
       } else {
         const int nsl = (V + 127) / 128, nmt = (B + 15) / 16;
         const dim3 vgrid(((nsl + 7) / 8) * 8 * nmt);
