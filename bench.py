@@ -269,6 +269,19 @@ def main():
                 hyp = rq.sentence_index(torch.from_numpy(gg["feat"]).to(dev)).cpu().numpy()
                 bleu[nm_] = _corpus_bleu4([list(map(int, r_)) for r_ in gg["greedy"]], [list(map(int, h_)) for h_ in hyp])
                 del rq
+            # HBM bytes per greedy step from the committed PMC passes of tools/time_decode.py (profiles/README.md, r01i):
+            # L fused-x cell launches + one vocabulary arg-max launch, 2*FETCH_SIZE + WRITE_SIZE each
+            dec_traffic = None
+            try:
+                import csv, glob
+                f_ = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_decode_hbm_traffic.csv")))[-1]
+                rows_ = [r_ for r_ in csv.reader(open(f_)) if r_]
+                cell_ = [float(r_[4]) for r_ in rows_ if r_[0].startswith("rnn_gemm_kernel<bool") and ", true, 1>" in r_[0]]
+                voc_ = [float(r_[4]) for r_ in rows_ if r_[0] == "vocab_argmax_lds_kernel"]
+                if cell_ and voc_:
+                    dec_traffic = round((L * cell_[0] + voc_[0]) * 1e6)
+            except Exception:
+                dec_traffic = None
             secondary = {"greedy_decode_us_per_step": round(us_step, 1),
                          "greedy_fp32_bleu4_vs_reference_vectors": round(bleu["fp32"], 4),
                          "greedy_bf16_bleu4_vs_reference_vectors": round(bleu["bf16"], 4),
@@ -277,7 +290,7 @@ def main():
                          "beam5_reference_vectors_images": nimg, "beam5_reference_nonempty": nonempty,
                          "greedy_algorithmic_MB_per_step": round(byts / 1e6, 2),
                          "greedy_hbm_roofline": {"bound": "hbm", "achieved": round(byts / us_step / 1e3, 1), "peak": 8000.0,
-                                                 "unit": "GB/s", "frac": round(byts / us_step / 1e3 / 8000.0, 4)},
+                                                 "unit": "GB/s", "frac": round(byts / us_step / 1e3 / 8000.0, 4), "traffic": dec_traffic},
                          "greedy_captions_per_sec": round(B / (us_step * 25e-6), 0),
                          "beam5_bs256_captions_per_sec": round(256 / tb, 0)}
             rnn.train()
