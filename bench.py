@@ -85,8 +85,8 @@ def _corpus_bleu4(refs, hyps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)    # >= 50 timed steps after 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE: 128)")
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--no-pipeline", action="store_true", help="do not issue the next minibatch's frozen backbone ahead on a second stream")
