@@ -102,6 +102,21 @@ def test_greedy_paths_agree(cell, name):
             assert np.array_equal(got[:, :64], first64)
 
 
+@pytest.mark.parametrize("B,V,H", [(128, 1000, 128), (130, 77, 64), (33, 4097, 128), (256, 520, 64), (5, 64, 64)])
+def test_fused_argmax_grid_shapes(B, V, H):
+    """The LDS-staged vocabulary arg-max runs on a 1-D grid in groups of 8 x ysplit blocks (row parts of one 64-entry slice
+    on the same XCD, padding blocks in the last group): ragged V, V below one group, row counts that do and do not split,
+    rows that are no multiple of 16.  Its tokens must equal the arg-max of the materialised logits (rnn.py:49-52)."""
+    params = R.init_decoder_params(H, H, V, 2, "gru", seed=11)
+    m = _make("gru", params, torch.float32).eval()
+    feat = torch.randn(B, H, generator=torch.Generator().manual_seed(11)).cuda()
+    ids_l, lg = m.sentence_index(feat, return_logits=True)
+    ids_f = m.sentence_index(feat)
+    assert ids_f.shape == (B, 25)
+    assert np.array_equal(lg.argmax(-1).cpu().numpy(), ids_l.cpu().numpy())
+    assert np.array_equal(ids_f.cpu().numpy(), ids_l.cpu().numpy())
+
+
 @pytest.mark.parametrize("cell", ["gru", "lstm"])
 def test_bf16_forward_backward_close_to_oracle(cell):
     E, H, V, L, B = 64, 64, 200, 3, 16
