@@ -32,8 +32,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
 ENC_GFLOP_PER_IMG = 15.60           # 7.7994 GMAC of convolution per 224x224 image
 
 
-def cpu_baseline(threads, B=8, budget_s=12.0):
-    """Oracle (CPU restatement, fp32) of the same train step; returns images/sec on `threads` cores."""
+def cpu_baseline(threads, B=8, budget_s=8.0, min_steps=3, warm=True):
+    """Oracle (CPU restatement, fp32) of the same train step; returns (images/sec, seconds, steps) on `threads` cores."""
     from oracle import restatement as R
     torch.set_num_threads(threads)
     enc = R.init_encoder_params(101, 512, seed=1)
@@ -53,14 +53,54 @@ def cpu_baseline(threads, B=8, budget_s=12.0):
             for k, t in list(dec.items()) + list(head.items()):
                 bufs[k] = R.sgd_momentum_step(t, t.grad, bufs.get(k), 0.01, 0.9)
                 t.grad = None
-    step()  # warm-up (allocations, thread pool)
+    if warm:
+        step()  # warm-up (allocations, thread pool)
     t0 = time.time()
     steps = 0
-    while steps < 3 or time.time() - t0 < budget_s:
+    while steps < min_steps or time.time() - t0 < budget_s:
         step()
         steps += 1
     dt = time.time() - t0
     return B * steps / dt, dt, steps
+
+
+def cpu_greedy_baseline(threads, B=128):
+    """Oracle greedy decode (rnn.py:37-58), 25 steps at the BASELINE decoder shape; returns (us per step, seconds)."""
+    from oracle import restatement as R
+    torch.set_num_threads(threads)
+    dec = R.init_decoder_params(512, 512, 10000, 5, "gru", seed=1)
+    feat = torch.randn(B, 512, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        R.rnn_greedy(dec, feat[:8], steps=2)
+        t0 = time.time()
+        R.rnn_greedy(dec, feat)
+        dt = time.time() - t0
+    return dt / 25 * 1e6, dt
+
+
+def encoder_algorithmic_bytes(B, es=2, size=224):
+    """HBM bytes one train-mode ResNet-101 forward must move when every fusion short of cross-layer on-chip residency is
+    made: each convolution reads its (already normalised or raw) input and its weights once and writes its raw output once
+    (batch statistics force that write: they must be complete before the output can be normalised); each block end reads the
+    raw conv3 output and the identity and writes the block output; the stem's BN + ReLU ride in the max pool."""
+    tot = 0
+    h = size // 2
+    tot += B * 3 * size * size * 4 + B * h * h * 64 * es            # stem conv: fp32 image in, raw out
+    tot += B * h * h * 64 * es + B * (h // 2) ** 2 * 64 * es        # max pool (with bn1 + relu)
+    h //= 2
+    inpl = 64
+    for planes, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 23, 2), (512, 3, 2)):
+        for bi in range(blocks):
+            s_ = stride if bi == 0 else 1
+            ho = h // s_
+            tot += (B * h * h * inpl + inpl * planes + B * h * h * planes) * es                      # conv1 1x1
+            tot += (B * h * h * planes + 9 * planes * planes + B * ho * ho * planes) * es            # conv2 3x3 (stride here, v1.5)
+            tot += (B * ho * ho * planes + 4 * planes * planes + B * ho * ho * 4 * planes) * es      # conv3 1x1
+            if bi == 0:
+                tot += (B * h * h * inpl + inpl * 4 * planes + B * ho * ho * 4 * planes) * es        # downsample 1x1
+            tot += 3 * B * ho * ho * 4 * planes * es                                                 # bn3 + identity + relu
+            inpl, h = 4 * planes, ho
+    return tot
 
 
 def _corpus_bleu4(refs, hyps):
@@ -82,6 +122,34 @@ def _corpus_bleu4(refs, hyps):
     return bp * math.exp(sum(math.log(a / b) for a, b in zip(num, den)) / 4.0)
 
 
+def self_launch(n):
+    """Run this script under torch.distributed.run with n ranks on this node (127.0.0.1 rendezvous, a free port)."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0 or line is None:
+        raise SystemExit(rc or 1)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +162,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU) BEFORE this
+        # process touches the GPU, relay rank 0's JSON line and the launcher's return code.  Never exec.
+        return self_launch(a.gpus)
 
     from showtell_amd import optim, parallel
     from showtell_amd._lib import lib
@@ -172,17 +245,18 @@ def main():
         # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process; the figure comes from the
         # committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command
         # (profiles/README.md; 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction), launch-weighted over the 128x128-tile forms
-        traffic = None
+        traffic = traffic_src = None
         try:
             import csv, glob
             f = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic.csv")))[-1]
+            traffic_src = "profiles/" + os.path.basename(f) + " (committed rocprofv3 --pmc passes of an earlier run of this command, NOT this run)"
             rows = [r for r in csv.reader(open(f)) if r and (r[0].startswith("igemm_kernel<bf16,128,128,2,4,") or r[0] == "igemm_s3b_kernel")]
             if v == 0 and rows:
                 traffic = round(sum(float(r[1]) * float(r[4]) for r in rows) / sum(float(r[1]) for r in rows) * 1e6)
         except Exception:
             traffic = None
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                 "kernel": names.get(v, f"variant{v}"), "launches": int(n[v]),
                 "avg_launch_us": round(ms[v] * 1e3 / max(1, n[v]), 2),
                 "all_igemm_TFLOPs": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
@@ -208,6 +282,11 @@ def main():
             torch.cuda.synchronize()
             names_ = ["encoder_forward", "head_decoder_forward_loss", "backward", "optimizer"]
             phases = {nm: round(sum(e[i].elapsed_time(e[i + 1]) for e in ev[1:]) / 2, 3) for i, nm in enumerate(names_)}
+            enc_s = phases["encoder_forward"] * 1e-3
+            enc_bytes = encoder_algorithmic_bytes(B)
+            phases["encoder_mfma_frac"] = round(ENC_GFLOP_PER_IMG * 1e9 * B / enc_s / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)   # whole forward, one in flight
+            phases["encoder_hbm_frac"] = round(enc_bytes / enc_s / 8e12, 4)
+            phases["encoder_algorithmic_GB"] = round(enc_bytes / 1e9, 2)
             phases["unit"] = "ms per plain step (no forwards in flight); the pipelined step overlaps the encoder of later minibatches with the rest"
         except Exception as e:
             phases = {"error": repr(e)}
@@ -271,7 +350,7 @@ def main():
                 del rq
             # HBM bytes per greedy step from the committed PMC passes of tools/time_decode.py (profiles/README.md, r01i):
             # L fused-x cell launches + one vocabulary arg-max launch, 2*FETCH_SIZE + WRITE_SIZE each
-            dec_traffic = None
+            dec_traffic = dec_traffic_src = None
             try:
                 import csv, glob
                 f_ = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_decode_hbm_traffic.csv")))[-1]
@@ -280,6 +359,7 @@ def main():
                 voc_ = [float(r_[4]) for r_ in rows_ if r_[0] == "vocab_argmax_lds_kernel"]
                 if cell_ and voc_:
                     dec_traffic = round((L * cell_[0] + voc_[0]) * 1e6)
+                    dec_traffic_src = "profiles/" + os.path.basename(f_) + " (committed PMC passes of an earlier run, NOT this run)"
             except Exception:
                 dec_traffic = None
             secondary = {"greedy_decode_us_per_step": round(us_step, 1),
@@ -290,9 +370,36 @@ def main():
                          "beam5_reference_vectors_images": nimg, "beam5_reference_nonempty": nonempty,
                          "greedy_algorithmic_MB_per_step": round(byts / 1e6, 2),
                          "greedy_hbm_roofline": {"bound": "hbm", "achieved": round(byts / us_step / 1e3, 1), "peak": 8000.0,
-                                                 "unit": "GB/s", "frac": round(byts / us_step / 1e3 / 8000.0, 4), "traffic": dec_traffic},
+                                                 "unit": "GB/s", "frac": round(byts / us_step / 1e3 / 8000.0, 4), "traffic": dec_traffic, "traffic_source": dec_traffic_src},
                          "greedy_captions_per_sec": round(B / (us_step * 25e-6), 0),
                          "beam5_bs256_captions_per_sec": round(256 / tb, 0)}
+            # Config 5 quality at the FULL decoder shape (E = H = 512, L = 5, V = 10000): beam-5 captions of the bf16 kernels
+            # scored with the reference's BLEU (evaluation.py:bleu_score = evaluation_metrics.py:117-317) against the fp32
+            # kernels' captions on the same weights, 32 images.  Random weights never emit <end>; its bias is raised so that
+            # <end> reaches the beam after a few words (the recipe of oracle/gen_golden.py), otherwise no hypothesis completes.
+            try:
+                from showtell_amd.evaluation import bleu_score
+                torch.manual_seed(5)
+                r32 = RNN(E, H, V, L, dtype=torch.float32)
+                with torch.no_grad():
+                    r32.linear.bias[2] += 0.9
+                sd_ = {k: v.clone() for k, v in r32.state_dict().items()}
+                r16 = RNN(E, H, V, L, dtype=torch.bfloat16); r16.load_state_dict(sd_)
+                r32, r16 = r32.to(dev).eval(), r16.to(dev).eval()
+                f32_ = torch.randn(32, E, device=dev)
+                h32, h16 = r32.beam_search(f32_, 5, 1, 25), r16.beam_search(f32_, 5, 1, 25)
+                gts = {i: [" ".join(map(str, h32[i][0][0])) if h32[i] else ""] for i in range(32)}
+                res = {i: [" ".join(map(str, h16[i][0][0])) if h16[i] else ""] for i in range(32)}
+                keep = [i for i in range(32) if gts[i][0]]
+                b4 = bleu_score({i: gts[i] for i in keep}, {i: res[i] for i in keep}, 4)[0][3] if keep else None
+                secondary["beam5_bf16_bleu4_vs_fp32_kernels_fullshape"] = None if b4 is None else round(b4, 4)
+                secondary["beam5_fullshape_images"] = 32
+                secondary["beam5_fullshape_fp32_completed"] = len(keep)
+                secondary["beam5_fullshape_exact_match"] = sum(int(gts[i] == res[i]) for i in range(32))
+                secondary["beam5_fullshape_mean_len"] = round(sum(len(gts[i][0].split()) for i in keep) / max(1, len(keep)), 1)
+                del r32, r16
+            except Exception as e:
+                secondary["beam5_fullshape_error"] = repr(e)
             rnn.train()
             # BASELINE configs[2]: soft-attention GRU decoder (Attention/main_attn.py), bs=64, alpha_c=1.0: train steps/sec
             try:
@@ -373,14 +480,25 @@ def main():
                           "final_loss": round(final_loss, 4)},
                "roofline": roof, "phases": phases, "secondary": secondary}
         if world == 1 and not a.no_cpu_baseline:
-            cores = min(os.cpu_count() or 1, 16)
+            ncpu = os.cpu_count() or 1
             try:
-                v, secs, nst = cpu_baseline(cores)
-                out["cpu_baseline"] = {"value": round(v, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-                                       "sample": "oracle/restatement.py (torch CPU fp32) on the same train step at B=8: %d timed "
-                                                 "steps after 1 warm-up, %.1f s" % (nst, secs)}
+                v, secs, nst = cpu_baseline(ncpu)
+                out["cpu_baseline"] = {"value": round(v, 2), "unit": "images/sec", "cores": ncpu, "kind": "port",
+                                       "sample": "oracle/restatement.py (torch CPU fp32) on the same train step at B=8 on all %d host "
+                                                 "cores: %d timed steps after 1 warm-up, %.1f s" % (ncpu, nst, secs)}
+                extra = {}
+                v8, s8, n8 = cpu_baseline(min(8, ncpu))
+                extra["train_B8_8cores_images_per_sec"] = round(v8, 2)
+                extra["train_B8_8cores_sample"] = "%d steps, %.1f s on %d cores" % (n8, s8, min(8, ncpu))
+                vb, sb, nb = cpu_baseline(ncpu, B=128, budget_s=0.0, min_steps=1, warm=False)
+                extra["train_B128_allcores_images_per_sec"] = round(vb, 2)
+                extra["train_B128_allcores_sample"] = "%d cold step at B=128 (the metric's batch), %.1f s on %d cores" % (nb, sb, ncpu)
+                us, sg = cpu_greedy_baseline(ncpu)
+                extra["greedy_decode_B128_us_per_step"] = round(us, 1)
+                extra["greedy_decode_sample"] = "25 steps, B=128, L=5, V=10000 fp32, %.1f s on %d cores" % (sg, ncpu)
+                out["cpu_baseline"]["more"] = extra
             except Exception as e:  # the baseline must never take the bench line down
-                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
+                out.setdefault("cpu_baseline", {"value": None, "unit": "images/sec", "cores": ncpu, "kind": "port"})["error"] = "failed: %r" % (e,)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

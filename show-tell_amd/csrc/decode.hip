@@ -504,11 +504,13 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
       if (H <= 64 * epc && H % (8 * epc) == 0 && rpp >= 16) {
         // LDS-staged form: activations once per block, projection matrix once chip-wide
         const size_t lds = (size_t)rpp * H * es + (size_t)4 * rpp * sizeof(unsigned long long);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {};                  // the attribute belongs to the (function, device) pair
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_argmax_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_argmax_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          attr_set = true;
+          attr_set[dev_] = true;
         }
         const dim3 vgrid(((V + 63) / 64 + 7) / 8 * 8 * ysplit);
         if (dt == ST_BF16)

@@ -793,11 +793,13 @@ int launch_(IgemmArgs* arr, int n, hipStream_t st) {
       (void)hipEventRecord(rec.e0, st);
     }
   }
-  static int attr_set = 0;
-  if (attr_set < lds && lds > 64 * 1024) {
+  static int attr_set[64] = {};                     // per (instantiation, device): the attribute is a per-device property
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (dev_ >= 0 && dev_ < 64 && attr_set[dev_] < lds && lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, KC, MODE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = lds;
+    attr_set[dev_] = lds;
   }
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KC, MODE>), dim3(a.nbm * a.nbn, n), dim3(64 * WM * WN), lds, st, grp);
   if (prof) {

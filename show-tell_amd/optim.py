@@ -24,6 +24,7 @@ class _FlatOptimizer:
         self.flat = None
         self.steps = 0
         self.grad_scale = 1.0
+        self._stashed = None
         self.param_groups = [{"params": params, "lr": lr}]
         if params[0].is_cuda:
             self._ensure_flat()
@@ -33,6 +34,15 @@ class _FlatOptimizer:
         moving the models to the GPU (main.py:96-111); `.cuda()` swaps every param.data."""
         params = self.params
         if self.flat is not None and all(p.data_ptr() == self.flat.data_ptr() + 4 * o for p, o in zip(params, self.offsets)):
+            # the data views are intact; `module.zero_grad()` (set_to_none=True by default) or a stray `p.grad = ...` may have
+            # replaced the gradient views -- re-point them, keeping whatever had been accumulated
+            for p, o in zip(params, self.offsets):
+                if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                    old_grad = p.grad
+                    view = self.flat_grad[o:o + p.numel()].view(p.shape)
+                    if old_grad is not None:
+                        view.copy_(old_grad.to(view.device))
+                    p.grad = view
             return
         dev = params[0].device
         if dev.type != "cuda":
@@ -56,6 +66,9 @@ class _FlatOptimizer:
                 p.grad.copy_(old_grad.to(dev))
         self._alloc_state(dev, old_state)
         self._sync_shadow(initial=True)
+        if self._stashed is not None:              # load_state_dict() came before the parameters reached the GPU (main.py:96-121)
+            sd, self._stashed = self._stashed, None
+            self._apply_state(sd)
 
     def _sync_shadow(self, initial=False):
         if self.shadow is None:
@@ -69,17 +82,74 @@ class _FlatOptimizer:
             p._st_shadow_ver, p._st_shadow_ptr = p._version, p.data_ptr()
 
     def zero_grad(self, set_to_none=False):
+        """Gradients stay views of the flat buffer (the all-reduce target); `set_to_none` is accepted and ignored."""
         self._ensure_flat()
         self.flat_grad.zero_()
 
+    # ---- state_dict in torch.optim's layout (main.py:121 / utils.py:131-138): per-parameter entries keyed by index ------
     def state_dict(self):
-        return {"state": {k: v for k, v in self._state().items()}, "param_groups": [{"lr": self.lr, **self._hyper()}],
-                "steps": self.steps}
+        """{'state': {i: {<per-tensor buffers>}}, 'param_groups': [{..., 'params': [0..n-1]}]} exactly as
+        torch.optim.SGD / Adam write it, so a checkpoint written here loads into the reference's optimizer and back."""
+        state = {}
+        if self.flat is not None and self.steps > 0:
+            flat_state = self._state()
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                ent = {k: v[o:o + p.numel()].view(p.shape).clone() for k, v in flat_state.items()}
+                ent.update(self._per_param_extra())
+                if ent:
+                    state[i] = ent
+        group = {"lr": self.param_groups[0]["lr"], **self._hyper(), "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        for k, v in sd["state"].items():
-            self._state()[k].copy_(v)
-        self.steps = int(sd.get("steps", 0))
+        if not isinstance(sd, dict) or "state" not in sd:
+            raise ValueError("optimizer state_dict needs a 'state' entry (torch.optim layout)")
+        if self.flat is None and not self.params[0].is_cuda:
+            self._stashed = sd                     # applied by _ensure_flat once `.cuda()` has run (reference order, main.py:96-121)
+            self._restore_hyper(sd)
+            return
+        self._ensure_flat()
+        self._apply_state(sd)
+
+    def _restore_hyper(self, sd):
+        groups = sd.get("param_groups") or []
+        if groups:
+            if len(groups) != 1:
+                raise ValueError("showtell_amd optimizers hold one parameter group, the checkpoint has %d" % len(groups))
+            g = groups[0]
+            if "params" in g and len(g["params"]) != len(self.params):
+                raise ValueError("optimizer checkpoint covers %d tensors, this optimizer %d" % (len(g["params"]), len(self.params)))
+            if "lr" in g:
+                self.lr = self.param_groups[0]["lr"] = float(g["lr"])
+            self._load_hyper(g)
+
+    def _apply_state(self, sd):
+        self._restore_hyper(sd)
+        state = sd["state"]
+        flat_state = self._state()
+        if state and all(isinstance(k, str) for k in state):
+            # round-1 flat layout: whole-buffer tensors keyed by name
+            for k, v in state.items():
+                if k not in flat_state or flat_state[k].numel() != v.numel():
+                    raise ValueError("flat optimizer state %r does not match this optimizer" % (k,))
+                flat_state[k].copy_(v.to(flat_state[k].device))
+            self.steps = int(sd.get("steps", 0))
+            return
+        steps = 0
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            ent = state.get(i, state.get(str(i)))
+            if ent is None:
+                continue                            # torch.optim creates state lazily: a tensor without a gradient so far has none
+            for k, buf in flat_state.items():
+                if k not in ent or ent[k] is None:
+                    raise ValueError("optimizer checkpoint entry %d lacks %r" % (i, k))
+                t = ent[k]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError("optimizer checkpoint entry %d: %r has shape %s, parameter %s" % (i, k, tuple(t.shape), tuple(p.shape)))
+                buf[o:o + p.numel()].copy_(t.reshape(-1).to(buf.device, torch.float32))
+            st = ent.get("step", None)
+            steps = max(steps, int(st.item() if torch.is_tensor(st) else st) if st is not None else 1)
+        self.steps = int(sd.get("steps", steps))
 
 
 class SGD(_FlatOptimizer):
@@ -97,7 +167,17 @@ class SGD(_FlatOptimizer):
         return {"momentum_buffer": self.buf} if self.buf is not None else {}
 
     def _hyper(self):
-        return {"momentum": self.momentum}
+        return {"momentum": self.momentum, "dampening": 0, "weight_decay": 0, "nesterov": False}
+
+    def _load_hyper(self, g):
+        if g.get("dampening", 0) or g.get("weight_decay", 0) or g.get("nesterov", False):
+            raise ValueError("showtell_amd SGD implements the reference's SGD(lr, momentum) only (main.py:98): no dampening / weight decay / nesterov")
+        self.momentum = float(g.get("momentum", self.momentum))
+        if self.momentum != 0 and self.buf is None and self.flat is not None:
+            self.buf = torch.zeros(self.n, device=self.flat.device)
+
+    def _per_param_extra(self):
+        return {}
 
     def step(self):
         self._ensure_flat()
@@ -124,7 +204,16 @@ class Adam(_FlatOptimizer):
         return {"exp_avg": self.m, "exp_avg_sq": self.v} if self.m is not None else {}
 
     def _hyper(self):
-        return {"betas": self.betas, "eps": self.eps}
+        return {"betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False}
+
+    def _load_hyper(self, g):
+        if g.get("weight_decay", 0) or g.get("amsgrad", False):
+            raise ValueError("showtell_amd Adam implements the reference's Adam(lr) only (main.py:100): no weight decay / amsgrad")
+        self.betas = tuple(float(b) for b in g.get("betas", self.betas))
+        self.eps = float(g.get("eps", self.eps))
+
+    def _per_param_extra(self):
+        return {"step": int(self.steps)}
 
     def step(self):
         self._ensure_flat()

@@ -35,6 +35,28 @@ def init_from_env(backend=None, device_index=None):
     return rank, world, local
 
 
+def broadcast_state(modules, optimizer=None, src=0):
+    """Rank `src`'s parameters and buffers to every rank (what DDP does at construction): replicas must start equal even
+    when the caller did not seed every rank identically.  In place, so views into the optimizer's flat buffer stay views."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    if optimizer is not None:
+        optimizer._ensure_flat()
+    with torch.no_grad():
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                if t.numel() == 0:
+                    continue
+                if t.dim() == 0:                      # 0-d buffers (num_batches_tracked) may be views of a counter array
+                    v = t.data.reshape(1).clone()
+                    dist.broadcast(v, src)
+                    t.data.copy_(v.reshape(()))
+                else:
+                    dist.broadcast(t.data, src)
+    if optimizer is not None:
+        optimizer._sync_shadow(initial=True)         # the bf16 copies the kernels read
+
+
 class GradAllReducer:
     """Asynchronous bucketed all-reduce(mean) of a flat gradient buffer."""
 

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .head import linear_bn1d
-from .parallel import GradAllReducer
+from .parallel import GradAllReducer, broadcast_state
 
 
 def synthetic_batch(B, V, seed=1, device="cuda", image_size=224, mean=12.5, std=2.5, lo=6, hi=25):
@@ -47,6 +47,8 @@ class Trainer:
     def __init__(self, cnn, rnn, optimizer, world_size=1):
         self.cnn, self.rnn, self.opt = cnn, rnn, optimizer
         self.reducer = GradAllReducer(world_size)
+        if world_size > 1:
+            broadcast_state([cnn, rnn], optimizer)         # replicas start from rank 0's weights and BN buffers
         self.pending = False
         self._pre = []        # FIFO of (images, pooled features, event): backbone forwards issued ahead on the side streams
         self._side = []

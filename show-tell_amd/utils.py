@@ -3,7 +3,8 @@
 ``create_checkpoint`` writes exactly the dictionary the reference writes (utils.py:125-145):
 ``{'encoder_state_dict', 'decoder_state_dict', 'optimizer_state_dict', 'epoch', 'step'}`` to
 ``<output_dir>/model_<epoch>.ckpt`` plus ``model_<epoch>_metrics.ckpt = {'train_loss': [...]}``; because
-the modules keep the reference's ``state_dict`` keys, checkpoints move both ways between the two code bases.
+the modules keep the reference's ``state_dict`` keys and the optimizers write torch.optim's per-parameter layout
+(optim.py), checkpoints move both ways between the two code bases.
 ``load_checkpoint`` mirrors main.py:117-123 / utils.py:151-154.  No kernels are involved: this is host I/O.
 """
 import os
@@ -11,8 +12,13 @@ import os
 import torch
 
 
-def create_checkpoint(cnn, rnn, optimizer, epoch, step, train_loss, params):
-    '''Function to create a checkpoint for the trained models and their corresponding evaluated metrics (utils.py:125).'''
+def create_checkpoint(cnn, rnn, optimizer, epoch, step, train_loss, params, trainer=None):
+    '''Function to create a checkpoint for the trained models and their corresponding evaluated metrics (utils.py:125).
+    `trainer`: a showtell_amd.train.Trainer whose last optimizer.step() may still be pending (it is applied after the NEXT
+    step's frozen backbone so that the gradient all-reduce hides behind it); it is flushed first so that the file holds what
+    the reference's loop would hold at this point.'''
+    if trainer is not None:
+        trainer.flush()
     model_file = 'model_' + str(epoch) + '.ckpt'
     metrics_file = 'model_' + str(epoch) + '_metrics.ckpt'
     os.makedirs(params['output_dir'], exist_ok=True)
@@ -32,10 +38,7 @@ def load_checkpoint(path, cnn, rnn, optimizer=None, map_location='cpu'):
     cnn.load_state_dict(sd['encoder_state_dict'])
     rnn.load_state_dict(sd['decoder_state_dict'])
     if optimizer is not None and sd.get('optimizer_state_dict'):
-        try:
-            optimizer.load_state_dict(sd['optimizer_state_dict'])
-        except Exception:
-            pass   # a torch.optim checkpoint carries per-tensor state; the flat optimizer restarts its moments
+        optimizer.load_state_dict(sd['optimizer_state_dict'])   # main.py:121; a mismatching checkpoint raises, as torch.optim's does
     return sd.get('epoch', 0), sd.get('step', 0)
 
 

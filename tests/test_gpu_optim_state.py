@@ -1,0 +1,93 @@
+"""Optimizer state through a checkpoint, the way the reference resumes (main.py:96-121: optimizer built on CPU parameters,
+models moved with .cuda(), THEN optimizer.load_state_dict): 3 steps + save + restore + 3 steps must equal 6 uninterrupted
+steps, for SGD(momentum) and Adam; the file is torch.optim's per-parameter layout and loads into torch.optim itself."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+E = H = 64
+L, V, B = 2, 120, 4
+
+
+def _build(kind, on_gpu_first):
+    from showtell_amd import optim
+    from showtell_amd.cnn import ResNet
+    from showtell_amd.rnn import RNN
+    from showtell_amd.train import Trainer
+    torch.manual_seed(21)
+    cnn, rnn = ResNet(18, E), RNN(E, H, V, L)
+    if on_gpu_first:
+        cnn, rnn = cnn.cuda(), rnn.cuda()
+    params = Trainer.trainable_params(cnn, rnn)
+    opt = optim.SGD(params, lr=0.05, momentum=0.9, shadow_dtype=None) if kind == "SGD" else optim.Adam(params, lr=1e-3, shadow_dtype=None)
+    return cnn, rnn, opt
+
+
+def _steps(cnn, rnn, opt, data):
+    from showtell_amd.train import Trainer
+    cnn.train(); rnn.train()
+    tr = Trainer(cnn, rnn, opt)
+    out = [float(tr.step(*d).detach()) for d in data]
+    tr.flush()
+    return out, tr
+
+
+@pytest.mark.parametrize("kind", ["SGD", "Adam"])
+def test_resume_equals_uninterrupted(tmp_path, kind):
+    from showtell_amd.train import synthetic_batch
+    from showtell_amd.utils import create_checkpoint, load_checkpoint
+    data = [synthetic_batch(B, V, seed=60 + i, image_size=96, mean=6, std=1.5, lo=4, hi=9) for i in range(6)]
+    cnn, rnn, opt = _build(kind, True)
+    full, _ = _steps(cnn, rnn, opt, data)
+    want = opt.flat.detach().cpu().clone()
+
+    cnn, rnn, opt = _build(kind, True)
+    first, tr = _steps(cnn, rnn, opt, data[:3])
+    path = create_checkpoint(cnn, rnn, opt, 0, 3, first, {"output_dir": str(tmp_path)}, trainer=tr)
+    sd = torch.load(path, weights_only=True)["optimizer_state_dict"]
+    assert set(sd) == {"state", "param_groups"} and all(isinstance(k, int) for k in sd["state"])
+    # the file loads into torch.optim's own optimizer over same-shaped tensors (the reference's resume path)
+    ref_params = [torch.nn.Parameter(torch.zeros_like(p, device="cpu")) for p in opt.params]
+    ref_opt = torch.optim.SGD(ref_params, lr=1.0, momentum=0.5) if kind == "SGD" else torch.optim.Adam(ref_params, lr=1.0)
+    ref_opt.load_state_dict(sd)
+    assert ref_opt.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+
+    # resume the reference's way: optimizer over CPU parameters, .cuda(), then load
+    cnn2, rnn2, opt2 = _build(kind, False)
+    cnn2, rnn2 = cnn2.cuda(), rnn2.cuda()
+    assert load_checkpoint(path, cnn2, rnn2, opt2) == (0, 3)
+    rest, _ = _steps(cnn2, rnn2, opt2, data[3:])
+    assert first + rest == pytest.approx(full, rel=1e-5, abs=1e-6)
+    got = opt2.flat.detach().cpu()
+    assert ((got - want).abs().max() / want.abs().max()).item() < 1e-5
+    # a torch.optim checkpoint (what the reference's runs leave behind) restores the flat buffers too
+    cnn3, rnn3, opt3 = _build(kind, False)
+    opt3.load_state_dict(ref_opt.state_dict())          # stashed: parameters are still on the CPU
+    cnn3, rnn3 = cnn3.cuda(), rnn3.cuda()
+    opt3.zero_grad()                                    # first use builds the flat buffers and applies the stash
+    assert opt3.steps > 0
+    for k, v in opt3._state().items():
+        assert torch.equal(v.cpu(), opt._state()[k].cpu()), k
+    # a checkpoint that does not fit raises instead of being swallowed
+    bad = {"state": {0: {("momentum_buffer" if kind == "SGD" else "exp_avg"): torch.zeros(3)}}, "param_groups": sd["param_groups"]}
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(bad)
+
+
+def test_module_zero_grad_does_not_detach_the_flat_gradient():
+    """module.zero_grad() (set_to_none=True) drops the gradient views; the next optimizer call must re-point them instead of
+    stepping on a zero buffer."""
+    from showtell_amd.train import synthetic_batch
+    cnn, rnn, opt = _build("SGD", True)
+    cnn.train(); rnn.train()
+    img, cap, lens = synthetic_batch(B, V, seed=70, image_size=96, mean=6, std=1.5, lo=4, hi=9)
+    opt.zero_grad()
+    rnn.zero_grad(); cnn.zero_grad()                    # the reference's loop could as well call these
+    assert rnn.linear.weight.grad is None
+    loss = rnn.loss(cnn(img), cap, lens)
+    loss.backward()
+    before = opt.flat.clone()
+    opt.step()
+    assert rnn.linear.weight.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * opt.offsets[[i for i, q in enumerate(opt.params) if q is rnn.linear.weight][0]]
+    assert float(opt.flat_grad.abs().max()) > 0 and not torch.equal(before, opt.flat)

@@ -52,3 +52,29 @@ def test_single_process_is_a_noop():
     t = torch.arange(5.0)
     red.start(t)
     assert red.finish() == 1.0 and torch.equal(t, torch.arange(5.0))
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from showtell_amd import parallel
+    parallel.init_from_env("gloo")
+    torch.manual_seed(rank)                                    # every rank starts from DIFFERENT weights and buffers
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))
+    with torch.no_grad():
+        m[1].running_mean.normal_(); m[1].num_batches_tracked.fill_(7 + rank)
+    parallel.broadcast_state([m], None)
+    torch.save(m.state_dict(), os.path.join(out_dir, f"sd{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_state_equalises_replicas(tmp_path):
+    """Trainer(world>1) starts every replica from rank 0's parameters AND buffers (what DDP does at construction)."""
+    world, port = 2, _free_port()
+    mp.spawn(_bcast_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(tmp_path / f"sd{r}.pt", weights_only=True) for r in range(world))
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3)).state_dict()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["0.weight"], ref["0.weight"]) and int(a["1.num_batches_tracked"]) == 7
