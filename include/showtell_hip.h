@@ -81,9 +81,39 @@ int st_conv(const st_conv_desc* d, void* stream);
  * per-layer weight-gradient GEMMs of the decoder backward (autograd of nn.GRU, main.py:151) are 48 tiles each. */
 int st_conv_batch(const st_conv_desc* d, int n, void* stream);
 
-/* Launch profiler for bench.py's roofline: HIP events around every st_conv launch on its stream.
- * st_prof_collect fills 8-entry arrays indexed by kernel variant (0: bf16 128x128 tile,
- * 1: bf16 128x64, 2: bf16 64x128, 4..6 the same for f32); synchronise the device first. */
+/* ------------------------------------------------------------------------------------
+ * Image-resident 3x3 stride-1 pad-1 convolution, bf16 (the conv2 of torchvision's Bottleneck / the convs of BasicBlock
+ * behind `self.model(x)`, reference cnn.py:46 / cnn_attn.py:46; csrc/conv_img.hip).  A workgroup keeps a band of one
+ * image (+ zero halo) in LDS for all nine taps, the filter bank streams fragment-major from HBM/L2 straight into MFMA
+ * operand registers, no barrier in the K loop.  x: [B][H][W][C] bf16 (dense), y: [B][H][W][N] bf16 (dense),
+ * w_frag: st_pack_conv_weight_frag(.., ntw = st_conv3x3_img_supported(H, W, C, N)).
+ *   in_stats != NULL: x is the RAW output of the producer convolution; the fill applies relu(batchnorm(x)) with the
+ *                     producer's batch statistics ([sum | sumsq] over in_count rows) once per element (bn1 + ReLU of
+ *                     the Bottleneck in train mode, main.py:125) -- the separate normalise pass disappears.
+ *   stats != NULL   : per-channel [sum(N) | sumsq(N)] of the fp32 results are added (stats_replicas as in st_conv_desc;
+ *                     the replica is (image, band) %% R).
+ *   scale/shift/relu: eval-mode epilogue y = relu?(acc * scale + shift).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; const void* w_frag; void* y;
+  float* stats; int stats_replicas;
+  const float* scale; const float* shift; int relu;
+  const float* in_stats; const float* in_gamma; const float* in_beta; float in_count; float in_eps;
+  int B, H, W, C, N;
+  int in_stats_replicas;   /* 0/1: in_stats is [2C]; R > 1: [R][2C], summed by the kernel (no reduction launch in between) */
+} st_conv3x3_img_desc;
+/* > 0: supported, the value is the `ntw` the weights must be packed with; 0: use st_conv */
+int st_conv3x3_img_supported(int H, int W, int C, int N);
+int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream);
+/* [Cout][Cin][KH][KW] fp32 (torch layout) -> fragment-major bf16: element ((T * KS + ks) * 64 + lane) * 8 + j is
+ * w[ch(T, lane & 15)][k = 32 ks + 8 (lane >> 4) + j] with k = (kh * KW + kw) * Cin + c and
+ * ch(T, r) = (T / ntw) * 16 ntw + 4 ntw (r / 4) + 4 (T %% ntw) + r %% 4: one coalesced 1-KiB load is one MFMA operand
+ * (16 output channels x 32 K), and a wave that owns ntw tiles ends with 4 ntw consecutive channels per lane. */
+int st_pack_conv_weight_frag(const float* w, void* out, int Cout, int Cin, int KH, int KW, int ntw, void* stream);
+
+/* Launch profiler for bench.py's roofline: HIP events around every convolution launch on its stream.
+ * st_prof_collect fills 16-entry arrays indexed by kernel variant (0: bf16 128x128 tile family,
+ * 1: bf16 128x64, 2: bf16 64x128, 3: 256x128, 4..7 the same for f32, 8: st_conv3x3_img; csrc/prof.h); synchronise the device first. */
 int st_tune(int reserved, int kc, int w8);   /* main-loop variant knobs for tools/bench_conv.py (row chunk count 4|8, block shape); -1 = keep */
 int st_prof_enable(int on);
 /* debug aid: per-block phase timestamps of st_conv launches (tools/conv_stamps.py); NULL = off (default) */
@@ -196,7 +226,10 @@ int st_resnet_feat_dim(const st_resnet* r);
 size_t st_resnet_weight_elems(const st_resnet* r);
 size_t st_resnet_bn_channels(const st_resnet* r);
 int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cout, int* k, int* stride, int* pad,
-                        int* cin_padded, size_t* weight_offset, size_t* bn_offset, int* k_order);
+                        int* cin_padded, size_t* weight_offset, size_t* bn_offset, int* k_order,
+                        size_t* frag_weight_offset, int* frag_ntw);
+/* frag_ntw > 0: layer i also needs a fragment-major copy of its filters at element offset frag_weight_offset
+ * (st_pack_conv_weight_frag(.., ntw = frag_ntw)) for the image-resident kernel; 0: none. */
 size_t st_resnet_workspace_bytes(const st_resnet* r, int B, int H, int W);
 int st_resnet_forward(const st_resnet* r, const float* images_nchw, int B, int H, int W,
                       const void* weights, const float* bn_gamma, const float* bn_beta,

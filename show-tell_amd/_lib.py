@@ -23,6 +23,12 @@ class ConvDesc(C.Structure):
                 ("in_stats", c_p), ("in_gamma", c_p), ("in_beta", c_p), ("in_count", c_f), ("in_eps", c_f), ("split_k", c_i)]
 
 
+class Conv3x3ImgDesc(C.Structure):
+    _fields_ = [("x", c_p), ("w_frag", c_p), ("y", c_p), ("stats", c_p), ("stats_replicas", c_i), ("scale", c_p), ("shift", c_p),
+                ("relu", c_i), ("in_stats", c_p), ("in_gamma", c_p), ("in_beta", c_p), ("in_count", c_f), ("in_eps", c_f),
+                ("B", c_i), ("H", c_i), ("W", c_i), ("C", c_i), ("N", c_i), ("in_stats_replicas", c_i)]
+
+
 class BnActDesc(C.Structure):
     _fields_ = [("x", c_p), ("y", c_p), ("res", c_p), ("stats", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("res_stats", c_p), ("res_gamma", c_p),
@@ -72,6 +78,9 @@ _SIGS = {
     "st_image_transform": ([C.POINTER(ImageBatchDesc), c_p], c_i),
     "st_conv": ([C.POINTER(ConvDesc), c_p], c_i),
     "st_conv_batch": ([C.POINTER(ConvDesc), c_i, c_p], c_i),
+    "st_conv3x3_img_supported": ([c_i, c_i, c_i, c_i], c_i),
+    "st_conv3x3_img": ([C.POINTER(Conv3x3ImgDesc), c_p], c_i),
+    "st_pack_conv_weight_frag": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_tune": ([c_i, c_i, c_i], c_i),
     "st_prof_enable": ([c_i], c_i),
     "st_debug_stamps": ([c_p], c_i),
@@ -121,7 +130,7 @@ _SIGS = {
     "st_resnet_feat_dim": ([c_p], c_i),
     "st_resnet_weight_elems": ([c_p], C.c_size_t),
     "st_resnet_bn_channels": ([c_p], C.c_size_t),
-    "st_resnet_conv_info": ([c_p, c_i] + [C.POINTER(c_i)] * 6 + [C.POINTER(C.c_size_t)] * 2 + [C.POINTER(c_i)], c_i),
+    "st_resnet_conv_info": ([c_p, c_i] + [C.POINTER(c_i)] * 6 + [C.POINTER(C.c_size_t)] * 2 + [C.POINTER(c_i), C.POINTER(C.c_size_t), C.POINTER(c_i)], c_i),
     "st_resnet_workspace_bytes": ([c_p, c_i, c_i, c_i], C.c_size_t),
     "st_resnet_forward": ([c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, C.c_size_t,
                            c_p, c_p, c_i, c_p, c_p], c_i),

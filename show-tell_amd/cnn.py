@@ -119,10 +119,11 @@ class _Backbone:
             for i in range(n):
                 v = [C.c_int() for _ in range(6)]
                 o = [C.c_size_t(), C.c_size_t()]
-                ko = C.c_int()
-                check(lib().st_resnet_conv_info(h, i, *[C.byref(a) for a in v], *[C.byref(a) for a in o], C.byref(ko)), "conv_info")
+                ko, fo, fn = C.c_int(), C.c_size_t(), C.c_int()
+                check(lib().st_resnet_conv_info(h, i, *[C.byref(a) for a in v], *[C.byref(a) for a in o], C.byref(ko), C.byref(fo), C.byref(fn)), "conv_info")
                 self.info.append(dict(cin=v[0].value, cout=v[1].value, k=v[2].value, stride=v[3].value, pad=v[4].value,
-                                      cin_p=v[5].value, woff=o[0].value, bnoff=o[1].value, korder=ko.value))
+                                      cin_p=v[5].value, woff=o[0].value, bnoff=o[1].value, korder=ko.value,
+                                      woff_frag=fo.value, ntw=fn.value))
                 conv = self.pairs[i][0]
                 assert tuple(conv.weight.shape) == (v[1].value, v[0].value, v[2].value, v[2].value)
         return self.handle
@@ -167,6 +168,9 @@ class _Backbone:
             check(lib().st_pack_conv_weight(C.c_void_p(w.data_ptr()), C.c_void_p(self.packed.data_ptr() + inf["woff"] * es),
                                             dt, inf["cout"], inf["cin"], inf["k"], inf["k"], inf["cin_p"], inf["korder"], st),
                   "st_pack_conv_weight")
+            if inf["ntw"] > 0:      # second, fragment-major copy for the image-resident 3x3 kernel (st_conv3x3_img)
+                check(lib().st_pack_conv_weight_frag(C.c_void_p(w.data_ptr()), C.c_void_p(self.packed.data_ptr() + inf["woff_frag"] * es),
+                                                     inf["cout"], inf["cin"], inf["k"], inf["k"], inf["ntw"], st), "st_pack_conv_weight_frag")
         self.packed_key = key
 
     def forward(self, x, train, want_pooled, want_ncp, pooled_dtype=torch.float32):

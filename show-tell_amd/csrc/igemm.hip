@@ -23,6 +23,7 @@
 //   * blockIdx is remapped so that blocks of one XCD walk neighbouring tiles
 //     (pixel tile major), sharing the activation rows in that XCD's L2.
 #include "common.h"
+#include "prof.h"
 
 #include <vector>
 #include <mutex>
@@ -33,7 +34,7 @@ namespace {
 
 // ---- optional launch profiler (bench.py roofline): HIP events around every igemm launch, on the
 // ---- launch stream.  Off by default; never touched on the normal path beyond one branch.
-constexpr int kVariants = 8;
+constexpr int kVariants = kProfVariants;
 struct ProfRec { hipEvent_t e0, e1; int variant; double flops; };
 bool g_prof_on = false;
 unsigned long long* g_stamps = nullptr;   // st_debug_stamps
@@ -877,6 +878,24 @@ int dispatch(IgemmArgs* arr, int n, hipStream_t st) {
 
 }  // namespace
 
+StProfScope::StProfScope(int variant, double flops, hipStream_t st) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec rec;
+  if (g_prof.size() < kProfMax && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
+    rec.variant = variant; rec.flops = flops;
+    (void)hipEventRecord(rec.e0, st);
+    idx = g_prof.size(); on = true;
+    g_prof.push_back(rec);
+  }
+}
+unsigned long long* st_debug_stamps_ptr() { return g_stamps; }
+void StProfScope::end(hipStream_t st) {
+  if (!on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (idx < g_prof.size()) (void)hipEventRecord(g_prof[idx].e1, st);
+}
+
 static int fill_args(const st_conv_desc* d, IgemmArgs& a) {
   ST_CHECK(d && d->x && d->w && d->y, "st_conv: null pointer");
   ST_CHECK(d->dtype == ST_F32 || d->dtype == ST_BF16, "st_conv: bad dtype %d", d->dtype);
@@ -978,7 +997,7 @@ extern "C" int st_prof_enable(int on) {
 }
 
 // Sums per kernel variant (0: bf16 128x128, 1: bf16 128x64, 2: bf16 64x128, 4..6: the f32 forms).
-// The caller must have synchronised the stream(s).  Arrays must hold 8 entries.
+// The caller must have synchronised the stream(s).  Arrays must hold 16 entries (prof.h lists the variants).
 extern "C" int st_prof_collect(double* ms, double* flops, long* launches) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int v = 0; v < kVariants; ++v) { ms[v] = 0; flops[v] = 0; launches[v] = 0; }

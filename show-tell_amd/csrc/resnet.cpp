@@ -18,8 +18,9 @@
 #include <mutex>
 #include <new>
 #include <string.h>
+#include <stdlib.h>
 
-struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; int korder; };
+struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; int korder; size_t woff_frag; int ntw; };   // woff_frag: fragment-major copy for st_conv3x3_img (ntw > 0)
 struct BlockL { int c1, c2, c3, ds; int stride; };  // indices into convs (c3 = -1 for basic blocks, ds = -1 if none)
 
 struct BnTable { int n; int end[160]; float count[160]; int soff[160]; int rep[160]; };   // soff: float offset of the layer's [rep][2C] statistics
@@ -109,9 +110,15 @@ extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
   r->cpad0 = epc;  // 3 input channels zero-padded to one 16-byte chunk
   auto add = [&](int cin, int cout, int k, int s, int p) {
     const int ch = dtype == ST_BF16 ? 64 : 32;
-    ConvL c{cin, cout, k, s, p, r->wtotal, r->bntotal, (k > 1 && cin % ch == 0) ? 1 : 0};
+    ConvL c{cin, cout, k, s, p, r->wtotal, r->bntotal, (k > 1 && cin % ch == 0) ? 1 : 0, 0, 0};
     const int cin_p = (cin == 3) ? r->cpad0 : cin;
     r->wtotal += (size_t)cout * k * k * cin_p;
+    // 3x3 stride-1 layers get a second, fragment-major copy of their filters for the image-resident kernel (bf16 only);
+    // which kernel runs is decided per call from the map size (224 x 224 is nominal: 8 x 8 asks "is there a kernel at all")
+    if (dtype == ST_BF16 && k == 3 && s == 1 && p == 1) {
+      c.ntw = st_conv3x3_img_supported(8, 8, cin, cout);
+      if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * 9 * cin; }
+    }
     r->bntotal += cout;
     r->convs.push_back(c);
     return (int)r->convs.size() - 1;
@@ -149,7 +156,8 @@ extern "C" size_t st_resnet_weight_elems(const st_resnet* r) { return r ? r->wto
 extern "C" size_t st_resnet_bn_channels(const st_resnet* r) { return r ? r->bntotal : 0; }
 
 extern "C" int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cout, int* k, int* stride, int* pad,
-                                   int* cin_padded, size_t* weight_offset, size_t* bn_offset, int* k_order) {
+                                   int* cin_padded, size_t* weight_offset, size_t* bn_offset, int* k_order,
+                                   size_t* frag_weight_offset, int* frag_ntw) {
   ST_CHECK(r && i >= 0 && i < (int)r->convs.size(), "st_resnet_conv_info: bad index %d", i);
   const ConvL& c = r->convs[i];
   if (cin) *cin = c.cin;
@@ -161,6 +169,8 @@ extern "C" int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cou
   if (weight_offset) *weight_offset = c.woff;
   if (bn_offset) *bn_offset = c.bnoff;
   if (k_order) *k_order = c.korder;
+  if (frag_weight_offset) *frag_weight_offset = c.woff_frag;
+  if (frag_ntw) *frag_ntw = c.ntw;
   return 0;
 }
 
@@ -243,6 +253,8 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     tab.end[i] = (int)(r->convs[i].bnoff + r->convs[i].cout); tab.count[i] = 1.f; tab.soff[i] = 0; tab.rep[i] = 1;
   }
   int stats_used = 0;   // floats handed out so far
+  static const bool img_env = [] { const char* e = getenv("ST_CONV_IMG"); return !e || atoi(e) != 0; }();
+  const bool use_img = img_env && dt == ST_BF16;   // ST_CONV_IMG=0: every 3x3 through st_conv (A/B switch)
 
   // conv: train -> raw output + statistics; eval -> folded BN (+residual)(+ReLU) in the epilogue
   // in_ci >= 0 (train): x is the RAW output of conv in_ci; this conv reads relu(bn_{in_ci}(x)) in its loader
@@ -280,7 +292,25 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     }
     *ho = d.Ho; *wo = d.Wo;
     tab.count[ci] = (float)((long)B * d.Ho * d.Wo);
-    if (st_conv(&d, stream)) return 1;
+    if (c.ntw > 0 && use_img && !d.residual && st_conv3x3_img_supported(hin, win, c.cin, c.cout) == c.ntw) {
+      // image-resident 3x3 (conv_img.hip): the producer's BatchNorm + ReLU ride in its fill, replicated statistics in and out
+      st_conv3x3_img_desc g;
+      memset(&g, 0, sizeof(g));
+      g.x = x; g.w_frag = reinterpret_cast<const char*>(weights) + c.woff_frag * es; g.y = y;
+      g.B = B; g.H = hin; g.W = win; g.C = c.cin; g.N = c.cout;
+      g.in_stats = d.in_stats; g.in_gamma = d.in_gamma; g.in_beta = d.in_beta; g.in_count = d.in_count; g.in_eps = d.in_eps;
+      g.in_stats_replicas = in_ci >= 0 ? tab.rep[in_ci] : 0;
+      g.scale = d.scale; g.shift = d.shift; g.relu = d.relu;
+      if (train) {
+        int rep = 1;
+        const long items = (long)B * ((hin * (win + 2) + 223) / 224);         // ~ workgroups along M
+        while (rep < 16 && items / (rep * 2) >= 4 && (rep * 2) * 2 * c.cout <= kStatsRepFloats) rep *= 2;
+        stats_used -= tab.rep[ci] * 2 * c.cout;                                // re-plan this layer's replicas
+        tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
+        g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
+      }
+      if (st_conv3x3_img(&g, stream)) return 1;
+    } else if (st_conv(&d, stream)) return 1;
     if (train && tab.rep[ci] > 1) {
       const int c2 = 2 * c.cout;
       hipLaunchKernelGGL(bn_reduce_replicas_kernel, dim3((c2 + 255) / 256), dim3(256), 0, st, stats + tab.soff[ci], tab.rep[ci], c2);
@@ -320,8 +350,11 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     const void* xin = wide[cur];
     if (r->bottleneck) {
       if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
-      if (train && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
-      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2)) return 1;
+      // train: bn1 + relu ride in conv2's fill when the image-resident kernel takes conv2 (one pass over the tensor less)
+      const ConvL& c2 = r->convs[b.c2];
+      const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h1, w1, c2.cin, c2.cout) == c2.ntw;
+      if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
+      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, fuse1 ? b.c1 : -1)) return 1;
       // train: bn2 + relu are applied by conv3's loader (no separate pass over the 3x3 output); needs whole 64-channel
       // (f32: 32) K tiles, which every bottleneck width satisfies
       const bool fuse2 = train && r->convs[b.c3].cin % 64 == 0;
@@ -335,13 +368,16 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
     } else {
       if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
-      if (train && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
+      const ConvL& c2 = r->convs[b.c2];
+      const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h1, w1, c2.cin, c2.cout) == c2.ntw;
+      if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       const void* res = xin;
       if (b.ds >= 0) {
         if (conv(b.ds, xin, h, w, wide[dsb], nullptr, 0, &hd, &wd)) return 1;
         res = wide[dsb];
       }
-      if (conv(b.c2, narrow[0], h1, w1, wide[oth], res, 1, &h3, &w3)) return 1;
+      // (eval mode hands the residual to the conv epilogue, which the image-resident kernel does not have: st_conv there)
+      if (conv(b.c2, narrow[0], h1, w1, wide[oth], res, 1, &h3, &w3, fuse1 ? b.c1 : -1)) return 1;
       if (train && bnact(b.c2, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
     }
     h = h3; w = w3; cur = oth;

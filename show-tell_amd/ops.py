@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ST_BF16, ST_F32, BnActDesc, ConvDesc, check, lib
+from ._lib import ST_BF16, ST_F32, BnActDesc, Conv3x3ImgDesc, ConvDesc, check, lib
 
 _DT = {torch.float32: ST_F32, torch.bfloat16: ST_BF16}
 
@@ -204,6 +204,38 @@ def transpose(x, ldy=None, out=None, colsum=None):
         out = torch.empty(cols, ldy, device=x.device, dtype=x.dtype)
     check(lib().st_transpose_colsum(_p(x), _p(out), _p(colsum), dt_code(x), rows, cols, x.stride(0), ldy, _stream()),
           "st_transpose_colsum")
+    return out
+
+
+def pack_conv_weight_frag(w, ntw):
+    """(Cout,Cin,KH,KW) fp32 torch layout -> fragment-major bf16 (st_pack_conv_weight_frag) for the image-resident kernels."""
+    _dev(w)
+    Cout, Cin, KH, KW = w.shape
+    out = torch.empty(Cout * KH * KW * Cin, device=w.device, dtype=torch.bfloat16)
+    check(lib().st_pack_conv_weight_frag(_p(w), _p(out), Cout, Cin, KH, KW, int(ntw), _stream()), "st_pack_conv_weight_frag")
+    return out
+
+
+def conv3x3_img_supported(H, W, C, N):
+    return int(lib().st_conv3x3_img_supported(H, W, C, N))
+
+
+def conv3x3_img(x, w_frag, N, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, in_bn=None, out=None):
+    """Image-resident 3x3 s1 p1 conv (st_conv3x3_img): x (B,H,W,C) bf16 NHWC, w_frag from pack_conv_weight_frag."""
+    _dev(x, w_frag, stats, scale, shift, out)
+    B, H, W, Cc = x.shape
+    if x.dtype != torch.bfloat16:
+        raise _lib.ShowTellHipError("conv3x3_img is a bf16 kernel")
+    if out is None:
+        out = torch.empty(B, H, W, N, device=x.device, dtype=torch.bfloat16)
+    d = Conv3x3ImgDesc(_p(x), _p(w_frag), _p(out), _p(stats), int(stats_replicas), _p(scale), _p(shift), int(relu),
+                       None, None, None, 0.0, 0.0, B, H, W, Cc, N, 0)
+    if in_bn is not None:
+        _dev(in_bn["stats"], in_bn["gamma"], in_bn["beta"])
+        d.in_stats, d.in_gamma, d.in_beta = in_bn["stats"].data_ptr(), in_bn["gamma"].data_ptr(), in_bn["beta"].data_ptr()
+        d.in_count, d.in_eps = float(in_bn["count"]), float(in_bn.get("eps", 1e-5))
+        d.in_stats_replicas = int(in_bn.get("replicas", 0))
+    check(lib().st_conv3x3_img(C.byref(d), _stream()), "st_conv3x3_img")
     return out
 
 

@@ -1,0 +1,112 @@
+"""st_conv3x3_img (csrc/conv_img.hip): the image-resident 3x3 convolution against torch's conv2d on the same bf16-rounded
+operands and against the implicit-GEMM kernel (st_conv) it replaces on those layers -- every ResNet bottleneck width,
+bands that split an image (28x28, 56x56), a ragged last band, tiny maps, with and without the fused input
+BatchNorm + ReLU, train-mode statistics and the eval-mode scale/shift/ReLU epilogue."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (B, H, W, C, N)
+CASES = [
+    (3, 14, 14, 256, 256),     # layer3 conv2: one image per workgroup
+    (2, 28, 28, 128, 128),     # layer2 conv2: 4 bands of 7 rows
+    (2, 56, 56, 64, 64),       # layer1 conv2: 14 bands of 4 rows, all filters in registers
+    (5, 7, 7, 512, 512),       # layer4 conv2
+    (2, 30, 30, 128, 256),     # ragged last band (7 + 7 + 7 + 7 + 2 rows), N > C
+    (3, 4, 4, 256, 128),       # tiny map (a 64x64 input image)
+    (1, 9, 5, 64, 128),        # non-square
+    (2, 16, 16, 512, 128),     # several bands at 512 channels
+]
+
+
+def _ops():
+    from showtell_amd import ops
+    return ops
+
+
+def _data(case, seed=0):
+    B, H, W, C, N = case
+    g = torch.Generator().manual_seed(1000 * seed + H * W + C)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.2 + 0.2).bfloat16()
+    w = (torch.randn(N, C, 3, 3, generator=g) / np.sqrt(9 * C)).bfloat16().float()
+    return x, w
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3x3_img_matches_conv2d_and_igemm(case):
+    ops = _ops()
+    B, H, W, C, N = case
+    ntw = ops.conv3x3_img_supported(H, W, C, N)
+    assert ntw > 0
+    x, w = _data(case)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, 1).permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda()
+    wf = ops.pack_conv_weight_frag(w.cuda(), ntw)
+    st = torch.zeros(2 * N, device="cuda")
+    y = ops.conv3x3_img(xd, wf, N, stats=st)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * scale
+    # the implicit-GEMM kernel on the same operands: both round ONE fp32 sum to bf16; sums differ only by association
+    s0 = torch.zeros(2 * N, device="cuda")
+    y0 = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16), 3, 3, 1, 1, stats=s0)
+    d = (y.float() - y0.float()).abs().max().item()
+    assert d <= 2.0 ** -7 * scale, d
+    assert (y != y0).float().mean().item() < 0.02       # a different summation order flips the last bit of a few outputs
+    r2 = ref.reshape(-1, N)
+    np.testing.assert_allclose(st[:N].cpu().numpy(), r2.sum(0).numpy(), rtol=2e-3, atol=2e-3 * scale * np.sqrt(r2.shape[0]))
+    np.testing.assert_allclose(st[N:].cpu().numpy(), (r2 * r2).sum(0).numpy(), rtol=2e-3)
+    np.testing.assert_allclose(st.cpu().numpy(), s0.cpu().numpy(), rtol=1e-4, atol=1e-3 * scale * np.sqrt(r2.shape[0]))
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[4], CASES[7]])
+def test_conv3x3_img_fused_input_bn_relu_equals_separate_pass(case):
+    """in_stats: the fill applies relu(batchnorm(x)) once per element; must equal bn_act followed by the plain kernel BIT
+    FOR BIT (same coefficients, same rounding point), halo included (padding stays zero, it is not relu(shift))."""
+    ops = _ops()
+    B, H, W, C, N = case
+    ntw = ops.conv3x3_img_supported(H, W, C, N)
+    x, w = _data(case, seed=1)
+    xd = x.cuda()
+    wf = ops.pack_conv_weight_frag(w.cuda(), ntw)
+    g = torch.Generator().manual_seed(7)
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    x2 = xd.float().reshape(-1, C)
+    stats = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).contiguous()
+    n = float(B * H * W)
+    y_sep = ops.conv3x3_img(ops.bn_act(xd, gam, bet, stats=stats, count=n, relu=True), wf, N)
+    s1 = torch.zeros(4, 2 * N, device="cuda")
+    y_fused = ops.conv3x3_img(xd, wf, N, stats=s1, stats_replicas=4, in_bn=dict(stats=stats, gamma=gam, beta=bet, count=n))
+    # replicated producer statistics ([R][2C], summed by the kernel's prologue): [stats, 0, 0] adds up exactly
+    rep = torch.zeros(3, 2 * C, device="cuda"); rep[1] = stats
+    y_rep = ops.conv3x3_img(xd, wf, N, in_bn=dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=3))
+    torch.cuda.synchronize()
+    assert torch.equal(y_sep, y_fused)
+    assert torch.equal(y_rep, y_fused)
+    xn = F.relu(F.batch_norm(x.float().permute(0, 3, 1, 2), None, None, gam.cpu(), bet.cpu(), True, 0.1, 1e-5)).bfloat16().float()
+    ref = F.conv2d(xn, w, None, 1, 1).permute(0, 2, 3, 1)
+    assert (y_fused.float().cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    tot = s1.sum(0).cpu()                                  # replicated statistics add up to the single-buffer ones
+    r2 = ref.reshape(-1, N)
+    np.testing.assert_allclose(tot[:N].numpy(), r2.sum(0).numpy(), rtol=5e-3, atol=5e-3 * ref.abs().max().item() * np.sqrt(r2.shape[0]))
+
+
+def test_conv3x3_img_eval_epilogue_and_errors():
+    ops = _ops()
+    from showtell_amd import ShowTellHipError
+    case = (2, 14, 14, 256, 256)
+    B, H, W, C, N = case
+    x, w = _data(case, seed=2)
+    wf = ops.pack_conv_weight_frag(w.cuda(), ops.conv3x3_img_supported(H, W, C, N))
+    g = torch.Generator().manual_seed(3)
+    sc, sh = (torch.rand(N, generator=g) + 0.5), torch.randn(N, generator=g) * 0.3
+    y = ops.conv3x3_img(x.cuda(), wf, N, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, 1).permute(0, 2, 3, 1) * sc + sh)
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    assert ops.conv3x3_img_supported(14, 14, 96, 128) == 0          # no kernel for that width: callers fall back to st_conv
+    assert ops.conv3x3_img_supported(300, 300, 512, 512) == 0       # a band of one row would not fit in LDS
+    with pytest.raises(ShowTellHipError):
+        ops.conv3x3_img(torch.zeros(1, 14, 14, 96, device="cuda", dtype=torch.bfloat16), wf, 128)

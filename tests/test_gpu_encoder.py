@@ -121,7 +121,11 @@ def test_attention_encoder_resnet101_train_mode():
     mb, pb = _make(101, torch.bfloat16, attn=True)          # bf16 storage: damped residual gains (see _make)
     mb.train()
     refb = R.encoder_attn_forward(pb, x, 101, train=True)
-    assert _rel(mb(x.cuda()), refb) < TOL[torch.bfloat16]
+    gotb = mb(x.cuda()).float().cpu()
+    # un-pooled features, 98 samples per channel in the last stage's batch statistics: 104 bf16 storage roundings
+    # (2^-9 each) random-walk to ~2 % per element, the maximum over 200 k elements sits at 4-5 sigma
+    assert ((gotb - refb).norm() / refb.norm()).item() < 3e-2
+    assert _rel(gotb, refb) < 0.15
 
 
 def test_bf16_amplification_is_a_weight_property():
@@ -136,6 +140,8 @@ def test_bf16_amplification_is_a_weight_property():
         m, _ = _make(101, torch.float32, damp=damp)
         m.eval()
         a, b = m.backbone_features(x.cuda()), m.backbone_features(xp.cuda())
-        out[damp] = ((a - b).abs().max() / a.abs().max()).item() / 2.0 ** -9
-    print(f"amplification of a 2^-9 input perturbation through ResNet-101 (eval): undamped x{out[False]:.1f}, damped x{out[True]:.1f}")
+        rel_in = ((x - xp).norm() / x.norm()).item()
+        out[damp] = ((a - b).norm() / a.norm()).item() / rel_in
+    print(f"relative (L2) growth of a bf16 input rounding through ResNet-101 (eval, fp32 kernels): "
+          f"undamped x{out[False]:.2f}, damped x{out[True]:.2f}")
     assert out[True] < out[False]
