@@ -105,6 +105,24 @@ typedef struct {
 /* > 0: supported, the value is the `ntw` the weights must be packed with; 0: use st_conv */
 int st_conv3x3_img_supported(int H, int W, int C, int N);
 int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream);
+/* ------------------------------------------------------------------------------------
+ * Pointwise (1x1, stride 1 or 2) convolution with the filter slice held in registers, bf16, C <= 512 input channels
+ * (conv3 / downsample of torchvision's Bottleneck and the narrow conv1s, reference cnn.py:46; csrc/conv_img.hip).
+ * x: [B][Hin][Win][C] bf16 (dense), y: [B][Ho][Wo][N] bf16 with Ho = (Hin - 1) / stride + 1;
+ * w_frag: st_pack_conv_weight_frag(.., KH = KW = 1, ntw = st_conv1x1_wreg_supported(C, N)).
+ * in_stats / stats / scale / shift / relu as in st_conv3x3_img_desc; residual must be NULL (reserved: an epilogue that adds a
+ * residual stays with st_conv).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; const void* w_frag; void* y; const void* residual;
+  float* stats; int stats_replicas;
+  const float* scale; const float* shift; int relu;
+  const float* in_stats; const float* in_gamma; const float* in_beta; float in_count; float in_eps; int in_stats_replicas;
+  int B, Hin, Win, C, N, stride;
+} st_conv1x1_wreg_desc;
+int st_conv1x1_wreg_supported(int C, int N);
+int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream);
+
 /* [Cout][Cin][KH][KW] fp32 (torch layout) -> fragment-major bf16: element ((T * KS + ks) * 64 + lane) * 8 + j is
  * w[ch(T, lane & 15)][k = 32 ks + 8 (lane >> 4) + j] with k = (kh * KW + kw) * Cin + c and
  * ch(T, r) = (T / ntw) * 16 ntw + 4 ntw (r / 4) + 4 (T %% ntw) + r %% 4: one coalesced 1-KiB load is one MFMA operand
@@ -113,7 +131,7 @@ int st_pack_conv_weight_frag(const float* w, void* out, int Cout, int Cin, int K
 
 /* Launch profiler for bench.py's roofline: HIP events around every convolution launch on its stream.
  * st_prof_collect fills 16-entry arrays indexed by kernel variant (0: bf16 128x128 tile family,
- * 1: bf16 128x64, 2: bf16 64x128, 3: 256x128, 4..7 the same for f32, 8: st_conv3x3_img; csrc/prof.h); synchronise the device first. */
+ * 1: bf16 128x64, 2: bf16 64x128, 3: 256x128, 4..7 the same for f32, 8: st_conv3x3_img, 9: st_conv1x1_wreg; csrc/prof.h); synchronise the device first. */
 int st_tune(int reserved, int kc, int w8);   /* main-loop variant knobs for tools/bench_conv.py (row chunk count 4|8, block shape); -1 = keep */
 int st_prof_enable(int on);
 /* debug aid: per-block phase timestamps of st_conv launches (tools/conv_stamps.py); NULL = off (default) */

@@ -29,6 +29,12 @@ class Conv3x3ImgDesc(C.Structure):
                 ("B", c_i), ("H", c_i), ("W", c_i), ("C", c_i), ("N", c_i), ("in_stats_replicas", c_i)]
 
 
+class Conv1x1WregDesc(C.Structure):
+    _fields_ = [("x", c_p), ("w_frag", c_p), ("y", c_p), ("residual", c_p), ("stats", c_p), ("stats_replicas", c_i), ("scale", c_p),
+                ("shift", c_p), ("relu", c_i), ("in_stats", c_p), ("in_gamma", c_p), ("in_beta", c_p), ("in_count", c_f), ("in_eps", c_f),
+                ("in_stats_replicas", c_i), ("B", c_i), ("Hin", c_i), ("Win", c_i), ("C", c_i), ("N", c_i), ("stride", c_i)]
+
+
 class BnActDesc(C.Structure):
     _fields_ = [("x", c_p), ("y", c_p), ("res", c_p), ("stats", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("res_stats", c_p), ("res_gamma", c_p),
@@ -80,6 +86,8 @@ _SIGS = {
     "st_conv_batch": ([C.POINTER(ConvDesc), c_i, c_p], c_i),
     "st_conv3x3_img_supported": ([c_i, c_i, c_i, c_i], c_i),
     "st_conv3x3_img": ([C.POINTER(Conv3x3ImgDesc), c_p], c_i),
+    "st_conv1x1_wreg_supported": ([c_i, c_i], c_i),
+    "st_conv1x1_wreg": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_pack_conv_weight_frag": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_tune": ([c_i, c_i, c_i], c_i),
     "st_prof_enable": ([c_i], c_i),

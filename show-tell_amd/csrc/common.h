@@ -32,8 +32,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   bf16_t b = (bf16_t)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
   return *reinterpret_cast<uint16_t*>(&b);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  // ONE v_cvt_pk_bf16_f32 (RNE, NaN-preserving); two scalar casts + shift + or compiled to four instructions
+  const bf16x2_ b = __builtin_convertvector(f32x2_{lo, hi}, bf16x2_);
+  return *reinterpret_cast<const uint32_t*>(&b);
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);

@@ -21,6 +21,8 @@
 // constant tap shift.
 #include "common.h"
 #include "prof.h"
+#include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -238,6 +240,214 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef IMG_STAMP
 }
 
+// =====================================================================================================================
+// Pointwise (1x1) convolution with the filter slice in REGISTERS: K <= 512 input channels (conv3 and the downsample
+// convs of torchvision's Bottleneck, the 64/256-channel conv1s of layer1; reference cnn.py:46).
+//   * a wave owns 16 NTW output channels for the whole launch and keeps their K x 16 NTW filter slice as MFMA operand
+//     fragments in K/32 x NTW x 4 VGPRs (read once, fragment-major: one coalesced 1-KiB load per operand);
+//   * the workgroup (4 waves = 64 NTW channels) walks a range of 16 TMS-row stages: the rows of stage s+1 are requested
+//     from HBM/L2 while stage s is multiplied, normalised on the way in (producer's BatchNorm + ReLU, once per element
+//     per channel slice), written to the other half of a two-stage LDS ring (rows padded to 2K + 32 bytes: conflict-
+//     free ds_read_b128) -- ONE barrier per stage, none inside it;
+//   * a lane ends with 4 NTW consecutive channels of a row: direct 8/16-byte stores, per-lane statistics partials are
+//     carried in registers across the whole range and reduced once (DPP + one atomic per channel per workgroup).
+// Small per-wave footprint (<= 128 VGPRs at K = 256, NTW = 2): two or more workgroups per CU overlap each other's stage edges.
+struct PwArgs {
+  const bf16_t* x; const bf16_t* w; bf16_t* y;
+  float* stats; int srep;
+  const float* scale; const float* shift; int relu;
+  const float* in_stats; const float* in_gamma; const float* in_beta; float in_count, in_eps; int in_srep;
+  int M, N, nbn, nstage, spb;            // rows, channels, channel slices, 16 TMS-row stages in all / per workgroup
+  int Hin, Win, Ho, Wo, stride;          // stride > 1: output row (b, ho, wo) reads input pixel (b, ho * stride, wo * stride)
+};
+
+// relu(x * sc + sh) on 8 bf16 (one 16-byte chunk), rounded once: the same arithmetic as bn_act's pass
+__device__ __forceinline__ void bn_relu_chunk(u32x4& v, const float* sc, const float* sh) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float lo = fmaxf(__uint_as_float(v[d] << 16) * sc[2 * d] + sh[2 * d], 0.f);
+    const float hi = fmaxf(__uint_as_float(v[d] & 0xffff0000u) * sc[2 * d + 1] + sh[2 * d + 1], 0.f);
+    v[d] = pack_bf16x2(lo, hi);
+  }
+}
+
+template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE>
+__global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
+  constexpr int PIX = 2 * K + 32;
+  constexpr int KS = K / 32;
+  constexpr int CH8 = K / 8;                  // 16-byte chunks per row
+  constexpr int SM = 16 * TMS;                // rows per stage
+  constexpr int RPP = 256 / CH8;              // rows per loader pass
+  constexpr int NL = SM / RPP;                // loads per thread per stage
+  static_assert(SM % RPP == 0 && NL >= 1, "stage/loader mismatch");
+  constexpr int STAGE_BYTES = SM * PIX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lid;
+  {
+    const int nblk = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int slice = lid % a.nbn, mb = lid / a.nbn;
+  const int s_begin = mb * a.spb;
+  const int s_end = s_begin + a.spb < a.nstage ? s_begin + a.spb : a.nstage;   // stages in [s_end, s_begin + spb) hold no rows (last block only)
+  if (s_begin >= s_end) return;
+
+  // ---- filter slice -> registers --------------------------------------------------------------------------------
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int T0 = (slice * 4 + wid) * NTW;
+  const u32x4* wl = reinterpret_cast<const u32x4*>(a.w) + lane;
+  u32x4 wq[KS][NTW];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wq[s][j] = wl[((size_t)(T0 + j) * KS + s) * 64];
+
+  // ---- loader state ---------------------------------------------------------------------------------------------
+  const int cch = tid % CH8, lrow = tid / CH8;
+  const bool xf = a.in_stats != nullptr;
+  float sc[8], sh[8];
+  // D register sets: the rows of the next D stages are in flight while a stage is multiplied (a stage is shorter than one
+  // HBM / L2 round trip: with one set every stage paid that round trip in full)
+  u32x4 ra[D][NL]; bool rok[D][NL];
+  auto gload = [&](u32x4 (&r)[NL], bool (&ok)[NL], int stage) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      // UNCONDITIONAL loads (rows past the end re-read the last row; their results are never stored): a load under a branch
+      // makes the compiler drain vmcnt at the join, which would serialise the prefetch
+      int m = stage * SM + lrow + i * RPP;
+      ok[i] = m < a.M && stage < s_end;            // stages past the range (the prefetch runs D ahead): every lane re-reads row M - 1
+      m = ok[i] ? m : a.M - 1;
+      long src = m;
+      if constexpr (STRIDED) {
+        const int hw = a.Ho * a.Wo, b = m / hw, rem = m - b * hw, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        src = ((long)b * a.Hin + ho * a.stride) * a.Win + wo * a.stride;
+      }
+      r[i] = *reinterpret_cast<const u32x4*>(a.x + src * K + cch * 8);
+    }
+  };
+  auto lstore = [&](u32x4 (&r)[NL], bool (&ok)[NL], int buf) {
+    char* base = smem + buf * STAGE_BYTES + lrow * PIX + cch * 16;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if (xf) bn_relu_chunk(r[i], sc, sh);
+      *reinterpret_cast<u32x4*>(base + i * RPP * PIX) = r[i];
+    }
+  };
+
+  gload(ra[0], rok[0], s_begin);
+  if (xf) {   // producer's BatchNorm coefficients (replicated statistics summed here), while the first rows are in flight
+    float* coef = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
+    const float inv = 1.0f / a.in_count;
+    for (int c = tid; c < K; c += 256) {
+      float sm = 0.f, sq = 0.f;
+      for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * K + c]; sq += a.in_stats[(size_t)r * 2 * K + K + c]; }
+      const float mean = sm * inv;
+      const float var = fmaxf(sq * inv - mean * mean, 0.f);
+      const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
+      coef[c] = scv; coef[K + c] = a.in_beta[c] - mean * scv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = coef[cch * 8 + e]; sh[e] = coef[K + cch * 8 + e]; }
+  }
+  lstore(ra[0], rok[0], 0);
+#pragma unroll
+  for (int j = 1; j <= D; ++j)                       // stage s_begin + j waits in register set j % D (always issued: counted waits)
+    gload(ra[j % D], rok[j % D], s_begin + j);
+  __syncthreads();
+
+  constexpr int NC = 4 * NTW;
+  const int cb = T0 * 16 + NC * q4;
+  float es[NC], ess[NC], scv[NC], shv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; scv[c] = 1.f; shv[c] = 0.f; }
+  if constexpr (AFFINE) {   // eval-mode scale / shift: loaded and WAITED FOR here -- a first use inside the loop would put vmcnt(0) there
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { scv[c] = a.scale[cb + c]; shv[c] = a.shift[cb + c]; }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(scv[c]), "+v"(shv[c]));
+  }
+  const char* abase = smem + r16 * PIX + q4 * 16;
+
+  // The host makes the range a multiple of D stages (rows past M are masked), so the D unrolled copies below form one
+  // straight-line body: every prefetch is issued on every path and the compiler's waits are COUNTED (vmcnt((D-1) NL + ..)).
+  // A load or a wait under a branch here collapses them to vmcnt(0) and with it the prefetch depth to one stage.
+  for (int s0 = s_begin; s0 < s_begin + a.spb; s0 += D) {
+#pragma unroll
+   for (int u = 0; u < D; ++u) {
+    const int s = s0 + u;
+    {
+    const int buf = (s - s_begin) & 1;
+    const char* ab = abase + buf * STAGE_BYTES;
+    f32x4 acc[TMS][NTW];
+#pragma unroll
+    for (int i = 0; i < TMS; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 fa[TMS];
+#pragma unroll
+      for (int i = 0; i < TMS; ++i) fa[i] = *reinterpret_cast<const u32x4*>(ab + i * 16 * PIX + ks * 64);
+#pragma unroll
+      for (int i = 0; i < TMS; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = mfma_bf16(wq[ks][j], fa[i], acc[i][j]);
+    }
+    // epilogue of the stage: straight from the accumulators
+#pragma unroll
+    for (int i = 0; i < TMS; ++i) {
+      const int m = s * SM + i * 16 + r16;
+      if (m < a.M) {
+        float v[NC];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
+        if constexpr (AFFINE) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) v[c] = v[c] * scv[c] + shv[c];
+          if (a.relu) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
+          }
+        }
+        const size_t off = (size_t)m * a.N + cb;
+        bf16_t* dst = a.y + off;
+        if constexpr (NTW == 1) {
+          *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        } else {
+#pragma unroll
+          for (int h = 0; h < NTW / 2; ++h)
+            *reinterpret_cast<u32x4*>(dst + 8 * h) = u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                                           pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+        }
+      }
+    }
+    // next stage: its register set -> the other ring half, then that set requests stage s + 1 + D
+    lstore(ra[(u + 1) % D], rok[(u + 1) % D], buf ^ 1);
+    gload(ra[(u + 1) % D], rok[(u + 1) % D], s + 1 + D);
+    __syncthreads();
+    }
+   }
+  }
+
+  if (a.stats) {
+    float* sdst = a.stats + (a.srep > 1 ? (size_t)(mb % a.srep) * 2 * a.N : 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
+    if (r16 == 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { atomicAdd(sdst + cb + c, es[c]); atomicAdd(sdst + a.N + cb + c, ess[c]); }
+    }
+  }
+}
+
 // ---- fragment-major filter bank ---------------------------------------------------------------------------------
 // out[((T * KS + ks) * 64 + lane) * 8 + j], T = 16-channel tile, ks = 32-deep K step (k = tap * Cin + c), lane = (q4, r16):
 // MFMA row r16 of tile T is output channel ch(T, r16) = (T / NTW) * 16 NTW + 4 NTW (r16 / 4) + 4 (T % NTW) + r16 % 4
@@ -326,6 +536,111 @@ extern "C" int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream) {
     case 512: return launch_img<512, 4, 2>(a, lds, st, flops);
   }
   st_set_error("st_conv3x3_img: no kernel for C=%d", d->C);
+  return 1;
+}
+
+namespace {
+struct PwCfg { int ntw, tms; };
+// instantiations (K, NTW, TMS); the 4-tile-per-wave forms (NTW = 4) halve the number of channel slices (each slice re-reads
+// and re-normalises the rows) at twice the registers
+inline bool pw_cfg(int K, int N, PwCfg* c) {
+  // tuning knob for tools/bench_conv_pw.py: ST_PW_CFG="ntw,tms" forces a form where it is legal
+  static const int force = [] { const char* e = getenv("ST_PW_CFG"); int a = 0, b = 0; if (e && sscanf(e, "%d,%d", &a, &b) == 2) return a * 100 + b; return 0; }();
+  if (N % 64 || (K != 64 && K != 128 && K != 256 && K != 512)) return false;
+  if (force) {
+    const int ntw = force / 100, tms = force % 100;
+    const bool ok = N % (64 * ntw) == 0 && ((ntw == 1 && (tms == 2 || tms == 4)) || (ntw == 2 && (tms == 2 || tms == 4)) || (ntw == 4 && tms == 4));
+    if (ok) { *c = PwCfg{ntw, tms}; return true; }
+  }
+  // forms picked per layer geometry from tools/sweep_pw.sh on MI355X (B = 128): (channel tiles per wave, row tiles per stage)
+  const bool n128 = N % 128 == 0;
+  switch (K) {
+    case 64:  *c = N == 64 ? PwCfg{1, 4} : PwCfg{2, 4}; return N == 64 || n128;
+    case 128: *c = n128 ? PwCfg{2, 2} : PwCfg{1, 2}; return true;
+    case 256: *c = n128 ? PwCfg{2, 4} : PwCfg{1, 2}; return true;
+    case 512: *c = PwCfg{1, 2}; return true;
+  }
+  return false;
+}
+
+template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE>
+int launch_pw___(PwArgs& a, hipStream_t st, double flops, bool xf) {
+  constexpr int SM = 16 * TMS, PIX = 2 * K + 32;
+  const int lds = 2 * SM * PIX + (xf ? 2 * K * (int)sizeof(float) : 0);
+  a.nbn = a.N / (64 * NTW);
+  a.nstage = (a.M + SM - 1) / SM;
+  int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ < 1) occ = 1;
+  int mbs = (256 * occ) / a.nbn; if (mbs < 1) mbs = 1; if (mbs > a.nstage) mbs = a.nstage;
+  a.spb = ((a.nstage + mbs - 1) / mbs + D - 1) / D * D;      // a multiple of the prefetch depth (kernel: straight-line unrolled body)
+  mbs = (a.nstage + a.spb - 1) / a.spb;
+  static int attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev] && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[dev] = 1;
+  }
+  StProfScope prof(9, flops, st);
+  hipLaunchKernelGGL((conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE>), dim3(mbs * a.nbn), dim3(256), lds, st, a);
+  prof.end(st);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+template <int K, int NTW, int TMS, int D, bool STRIDED>
+int launch_pw__(PwArgs& a, hipStream_t st, double flops, bool xf) {
+  return a.scale ? launch_pw___<K, NTW, TMS, D, STRIDED, true>(a, st, flops, xf) : launch_pw___<K, NTW, TMS, D, STRIDED, false>(a, st, flops, xf);
+}
+
+template <int K, int NTW, int TMS, int D>
+int launch_pw_(PwArgs& a, hipStream_t st, double flops, bool xf) {
+  return a.stride > 1 ? launch_pw__<K, NTW, TMS, D, true>(a, st, flops, xf) : launch_pw__<K, NTW, TMS, D, false>(a, st, flops, xf);
+}
+
+template <int K, int NTW, int TMS>
+int launch_pw(PwArgs& a, hipStream_t st, double flops, bool xf) {
+  static const int depth = [] { const char* e = getenv("ST_PW_DEPTH"); return e ? atoi(e) : 0; }();   // tuning knob: register prefetch depth 2 | 3
+  constexpr int NL = 16 * TMS * K / 2048;             // 16-byte loads per thread per stage
+  if constexpr (NL <= 8) { if (depth == 3 || (depth == 0 && NL <= 4)) return launch_pw_<K, NTW, TMS, 3>(a, st, flops, xf); }
+  return launch_pw_<K, NTW, TMS, 2>(a, st, flops, xf);
+}
+}  // namespace
+
+// > 0: supported, the value is the `ntw` of the fragment-major weights (st_pack_conv_weight_frag with KH = KW = 1); 0: use st_conv
+extern "C" int st_conv1x1_wreg_supported(int K, int N) {
+  PwCfg c;
+  return pw_cfg(K, N, &c) ? c.ntw : 0;
+}
+
+extern "C" int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream) {
+  ST_CHECK(d && d->x && d->w_frag && d->y, "st_conv1x1_wreg: null pointer");
+  PwCfg c;
+  ST_CHECK(pw_cfg(d->C, d->N, &c), "st_conv1x1_wreg: unsupported geometry C=%d N=%d", d->C, d->N);
+  ST_CHECK(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->stride >= 1, "st_conv1x1_wreg: bad geometry");
+  ST_CHECK((d->scale == nullptr) == (d->shift == nullptr), "st_conv1x1_wreg: scale and shift go together");
+  ST_CHECK(d->scale || !d->relu, "st_conv1x1_wreg: relu comes with the eval-mode scale / shift epilogue");
+  ST_CHECK(!d->residual, "st_conv1x1_wreg: no residual input (a load in the epilogue would drain the row prefetch): use st_conv");
+  ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f), "st_conv1x1_wreg: input transform needs gamma, beta, count");
+  ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->in_stats_replicas >= 0 && d->in_stats_replicas <= 1024, "st_conv1x1_wreg: bad stats_replicas");
+  PwArgs a;
+  a.x = reinterpret_cast<const bf16_t*>(d->x); a.w = reinterpret_cast<const bf16_t*>(d->w_frag); a.y = reinterpret_cast<bf16_t*>(d->y);
+  a.stats = d->stats; a.srep = d->stats_replicas; a.scale = d->scale; a.shift = d->shift; a.relu = d->relu;
+  a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_count = d->in_count; a.in_eps = d->in_eps;
+  a.in_srep = d->in_stats_replicas > 1 ? d->in_stats_replicas : 1;
+  a.Hin = d->Hin; a.Win = d->Win; a.stride = d->stride;
+  a.Ho = (d->Hin - 1) / d->stride + 1; a.Wo = (d->Win - 1) / d->stride + 1;
+  const long M = (long)d->B * a.Ho * a.Wo;
+  ST_CHECK(M * (d->C > d->N ? d->C : d->N) < (1L << 40) && M < (1L << 31) - 4096, "st_conv1x1_wreg: too many rows");
+  a.M = (int)M; a.N = d->N;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const double flops = 2.0 * (double)M * d->N * d->C;
+  const bool xf = d->in_stats != nullptr;
+#define PW_CASE(KK, NT, TS) if (d->C == KK && c.ntw == NT && c.tms == TS) return launch_pw<KK, NT, TS>(a, st, flops, xf)
+#define PW_K(KK) PW_CASE(KK, 1, 2); PW_CASE(KK, 1, 4); PW_CASE(KK, 2, 2); PW_CASE(KK, 2, 4); PW_CASE(KK, 4, 4)
+  PW_K(64); PW_K(128); PW_K(256); PW_K(512);
+  PW_CASE(64, 1, 8);
+#undef PW_K
+#undef PW_CASE
+  st_set_error("st_conv1x1_wreg: no kernel for C=%d ntw=%d", d->C, c.ntw);
   return 1;
 }
 

@@ -119,6 +119,12 @@ extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
       c.ntw = st_conv3x3_img_supported(8, 8, cin, cout);
       if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * 9 * cin; }
     }
+    // pointwise layers with <= 512 input channels: fragment-major copy for the register-resident-filter kernel (st_conv1x1_wreg);
+    // the stride-2 512-channel downsample stays with st_conv (measured slower there)
+    if (dtype == ST_BF16 && k == 1 && p == 0 && !(s == 2 && cin == 512)) {
+      c.ntw = st_conv1x1_wreg_supported(cin, cout);
+      if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * cin; }
+    }
     r->bntotal += cout;
     r->convs.push_back(c);
     return (int)r->convs.size() - 1;
@@ -258,8 +264,9 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
 
   // conv: train -> raw output + statistics; eval -> folded BN (+residual)(+ReLU) in the epilogue
   // in_ci >= 0 (train): x is the RAW output of conv in_ci; this conv reads relu(bn_{in_ci}(x)) in its loader
+  // keep_rep: the consumer of this layer's statistics sums the replicas itself (conv_img.hip kernels): no reduction launch
   auto conv = [&](int ci, const void* x, int hin, int win, void* y, const void* eval_res, int eval_relu,
-                  int* ho, int* wo, int in_ci = -1) -> int {
+                  int* ho, int* wo, int in_ci = -1, bool keep_rep = false) -> int {
     const ConvL& c = r->convs[ci];
     st_conv_desc d;
     memset(&d, 0, sizeof(d));
@@ -292,7 +299,24 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     }
     *ho = d.Ho; *wo = d.Wo;
     tab.count[ci] = (float)((long)B * d.Ho * d.Wo);
-    if (c.ntw > 0 && use_img && !d.residual && st_conv3x3_img_supported(hin, win, c.cin, c.cout) == c.ntw) {
+    if (c.ntw > 0 && c.k == 1 && use_img && !d.residual) {
+      // pointwise, filter slice in registers (conv_img.hip): producer's BatchNorm + ReLU in the row loader, replicated statistics
+      st_conv1x1_wreg_desc g;
+      memset(&g, 0, sizeof(g));
+      g.x = x; g.w_frag = reinterpret_cast<const char*>(weights) + c.woff_frag * es; g.y = y;
+      g.B = B; g.Hin = hin; g.Win = win; g.C = c.cin; g.N = c.cout; g.stride = c.stride;
+      g.in_stats = d.in_stats; g.in_gamma = d.in_gamma; g.in_beta = d.in_beta; g.in_count = d.in_count; g.in_eps = d.in_eps;
+      g.in_stats_replicas = in_ci >= 0 ? tab.rep[in_ci] : 0;
+      g.scale = d.scale; g.shift = d.shift; g.relu = d.relu;
+      if (train) {
+        int rep = 1;
+        while (rep < 16 && (rep * 2) * 2 * c.cout <= kStatsRepFloats) rep *= 2;
+        stats_used -= tab.rep[ci] * 2 * c.cout;
+        tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
+        g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
+      }
+      if (st_conv1x1_wreg(&g, stream)) return 1;
+    } else if (c.ntw > 0 && c.k == 3 && use_img && !d.residual && st_conv3x3_img_supported(hin, win, c.cin, c.cout) == c.ntw) {
       // image-resident 3x3 (conv_img.hip): the producer's BatchNorm + ReLU ride in its fill, replicated statistics in and out
       st_conv3x3_img_desc g;
       memset(&g, 0, sizeof(g));
@@ -311,7 +335,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       }
       if (st_conv3x3_img(&g, stream)) return 1;
     } else if (st_conv(&d, stream)) return 1;
-    if (train && tab.rep[ci] > 1) {
+    if (train && tab.rep[ci] > 1 && !keep_rep) {
       const int c2 = 2 * c.cout;
       hipLaunchKernelGGL(bn_reduce_replicas_kernel, dim3((c2 + 255) / 256), dim3(256), 0, st, stats + tab.soff[ci], tab.rep[ci], c2);
       ST_LAUNCH_CHECK();
@@ -349,12 +373,14 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     int h1, w1, h2, w2, h3, w3, hd, wd;
     const void* xin = wide[cur];
     if (r->bottleneck) {
-      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
       // train: bn1 + relu ride in conv2's fill when the image-resident kernel takes conv2 (one pass over the tensor less)
       const ConvL& c2 = r->convs[b.c2];
-      const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h1, w1, c2.cin, c2.cout) == c2.ntw;
+      const ConvL& c3 = r->convs[b.c3];
+      const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h, w, c2.cin, c2.cout) == c2.ntw;   // conv1 keeps the map size
+      const bool c3_sums = train && use_img && c3.ntw > 0;       // conv3 on st_conv1x1_wreg: sums conv2's replicated statistics itself
+      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1, -1, fuse1)) return 1;
       if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
-      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, fuse1 ? b.c1 : -1)) return 1;
+      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, fuse1 ? b.c1 : -1, c3_sums)) return 1;
       // train: bn2 + relu are applied by conv3's loader (no separate pass over the 3x3 output); needs whole 64-channel
       // (f32: 32) K tiles, which every bottleneck width satisfies
       const bool fuse2 = train && r->convs[b.c3].cin % 64 == 0;
@@ -367,9 +393,11 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       if (conv(b.c3, narrow[1], h2, w2, wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
       if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
     } else {
-      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
+      const ConvL& c1 = r->convs[b.c1];
       const ConvL& c2 = r->convs[b.c2];
-      const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h1, w1, c2.cin, c2.cout) == c2.ntw;
+      const int h1p = conv_out(h, c1.k, c1.stride, c1.pad), w1p = conv_out(w, c1.k, c1.stride, c1.pad);
+      const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h1p, w1p, c2.cin, c2.cout) == c2.ntw;
+      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1, -1, fuse1)) return 1;
       if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       const void* res = xin;
       if (b.ds >= 0) {

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ST_BF16, ST_F32, BnActDesc, Conv3x3ImgDesc, ConvDesc, check, lib
+from ._lib import ST_BF16, ST_F32, BnActDesc, Conv1x1WregDesc, Conv3x3ImgDesc, ConvDesc, check, lib
 
 _DT = {torch.float32: ST_F32, torch.bfloat16: ST_BF16}
 
@@ -236,6 +236,30 @@ def conv3x3_img(x, w_frag, N, stats=None, stats_replicas=0, scale=None, shift=No
         d.in_count, d.in_eps = float(in_bn["count"]), float(in_bn.get("eps", 1e-5))
         d.in_stats_replicas = int(in_bn.get("replicas", 0))
     check(lib().st_conv3x3_img(C.byref(d), _stream()), "st_conv3x3_img")
+    return out
+
+
+def conv1x1_wreg_supported(Cin, N):
+    return int(lib().st_conv1x1_wreg_supported(Cin, N))
+
+
+def conv1x1_wreg(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, residual=None, in_bn=None, out=None):
+    """Register-resident-filter 1x1 conv (st_conv1x1_wreg): x (B,H,W,C) bf16 NHWC, w_frag from pack_conv_weight_frag(w (N,C,1,1))."""
+    _dev(x, w_frag, stats, scale, shift, residual, out)
+    B, H, W, Cc = x.shape
+    if x.dtype != torch.bfloat16:
+        raise _lib.ShowTellHipError("conv1x1_wreg is a bf16 kernel")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, N, device=x.device, dtype=torch.bfloat16)
+    d = Conv1x1WregDesc(_p(x), _p(w_frag), _p(out), _p(residual), _p(stats), int(stats_replicas), _p(scale), _p(shift), int(relu),
+                        None, None, None, 0.0, 0.0, 0, B, H, W, Cc, N, int(stride))
+    if in_bn is not None:
+        _dev(in_bn["stats"], in_bn["gamma"], in_bn["beta"])
+        d.in_stats, d.in_gamma, d.in_beta = in_bn["stats"].data_ptr(), in_bn["gamma"].data_ptr(), in_bn["beta"].data_ptr()
+        d.in_count, d.in_eps = float(in_bn["count"]), float(in_bn.get("eps", 1e-5))
+        d.in_stats_replicas = int(in_bn.get("replicas", 0))
+    check(lib().st_conv1x1_wreg(C.byref(d), _stream()), "st_conv1x1_wreg")
     return out
 
 

@@ -110,3 +110,83 @@ def test_conv3x3_img_eval_epilogue_and_errors():
     assert ops.conv3x3_img_supported(300, 300, 512, 512) == 0       # a band of one row would not fit in LDS
     with pytest.raises(ShowTellHipError):
         ops.conv3x3_img(torch.zeros(1, 14, 14, 96, device="cuda", dtype=torch.bfloat16), wf, 128)
+
+
+# ---- st_conv1x1_wreg: (B, H, W, C, N, stride) -----------------------------------------------------------------------
+PW_CASES = [
+    (3, 14, 14, 256, 1024, 1),    # layer3 conv3
+    (2, 56, 56, 64, 256, 1),      # layer1 conv3 / downsample
+    (2, 56, 56, 64, 64, 1),       # layer1 conv1 of block 0
+    (2, 56, 56, 256, 64, 1),      # layer1 conv1
+    (2, 28, 28, 128, 512, 1),     # layer2 conv3
+    (2, 28, 28, 512, 128, 1),     # layer2 conv1
+    (3, 28, 28, 512, 1024, 2),    # layer3 downsample (stride 2)
+    (2, 56, 56, 256, 512, 2),     # layer2 downsample
+    (5, 7, 7, 512, 2048, 1),      # layer4 conv3, ragged rows
+    (1, 5, 3, 256, 128, 1),       # a single ragged stage
+    (2, 9, 9, 256, 128, 2),       # odd map, stride 2
+]
+
+
+def _pw_data(case, seed=0):
+    B, H, W, C, N, s = case
+    g = torch.Generator().manual_seed(77 * seed + H * W + C + N)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.2 + 0.2).bfloat16()
+    w = (torch.randn(N, C, 1, 1, generator=g) / np.sqrt(C)).bfloat16().float()
+    return x, w
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_conv1x1_wreg_matches_conv2d_and_igemm(case):
+    ops = _ops()
+    B, H, W, C, N, s = case
+    ntw = ops.conv1x1_wreg_supported(C, N)
+    assert ntw > 0
+    x, w = _pw_data(case)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, s, 0).permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda()
+    wf = ops.pack_conv_weight_frag(w.cuda(), ntw)
+    R = 4
+    st = torch.zeros(R, 2 * N, device="cuda")
+    y = ops.conv1x1_wreg(xd, wf, N, stride=s, stats=st, stats_replicas=R)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert y.shape == ref.shape
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * scale
+    s0 = torch.zeros(2 * N, device="cuda")
+    y0 = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16), 1, 1, s, 0, stats=s0)
+    assert (y.float() - y0.float()).abs().max().item() <= 2.0 ** -7 * scale
+    assert (y != y0).float().mean().item() < 0.02
+    r2 = ref.reshape(-1, N)
+    tot = st.sum(0).cpu().numpy()
+    np.testing.assert_allclose(tot[:N], r2.sum(0).numpy(), rtol=2e-3, atol=2e-3 * scale * np.sqrt(r2.shape[0]))
+    np.testing.assert_allclose(tot[N:], (r2 * r2).sum(0).numpy(), rtol=2e-3)
+    np.testing.assert_allclose(tot, s0.cpu().numpy(), rtol=1e-4, atol=1e-3 * scale * np.sqrt(r2.shape[0]))
+
+
+@pytest.mark.parametrize("case", [PW_CASES[0], PW_CASES[1], PW_CASES[4], PW_CASES[5], PW_CASES[8]])
+def test_conv1x1_wreg_fused_input_bn_relu_and_eval_epilogue(case):
+    ops = _ops()
+    B, H, W, C, N, s = case
+    ntw = ops.conv1x1_wreg_supported(C, N)
+    x, w = _pw_data(case, seed=1)
+    xd = x.cuda()
+    wf = ops.pack_conv_weight_frag(w.cuda(), ntw)
+    g = torch.Generator().manual_seed(9)
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    x2 = xd.float().reshape(-1, C)
+    stats = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).contiguous()
+    n = float(B * H * W)
+    y_sep = ops.conv1x1_wreg(ops.bn_act(xd, gam, bet, stats=stats, count=n, relu=True), wf, N, stride=s)
+    rep = torch.zeros(3, 2 * C, device="cuda"); rep[2] = stats
+    y_fused = ops.conv1x1_wreg(xd, wf, N, stride=s, in_bn=dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=3))
+    torch.cuda.synchronize()
+    assert torch.equal(y_sep, y_fused)                      # same coefficients, same rounding point as the separate pass
+    # eval-mode epilogue: scale / shift, ReLU (the residual form of the Bottleneck's last conv stays with st_conv)
+    sc, sh = (torch.rand(N, generator=g) + 0.5), torch.randn(N, generator=g) * 0.3
+    y = ops.conv1x1_wreg(xd, wf, N, stride=s, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w, None, s, 0).permute(0, 2, 3, 1) * sc + sh)
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    from showtell_amd import ShowTellHipError
+    with pytest.raises(ShowTellHipError):
+        ops.conv1x1_wreg(xd, wf, N, stride=s, residual=y)

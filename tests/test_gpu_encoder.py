@@ -117,7 +117,10 @@ def test_attention_encoder_resnet101_train_mode():
     ref = R.encoder_attn_forward(params, x, 101, train=True)
     got = m(x.cuda())
     assert got.shape == (2, 2048, 49) and got.dtype == torch.float32
-    assert _rel(got, ref) < 1e-3
+    # un-pooled map, undamped weights, 98 samples per channel: the re-associated fp32 sums (atomics included) of 104 layers
+    # show up at ~1e-4 of the scale in the L2 sense; the maximum over 200 k elements sits a decade above that
+    assert ((got.float().cpu() - ref).norm() / ref.norm()).item() < 3e-4
+    assert _rel(got, ref) < 3e-3
     mb, pb = _make(101, torch.bfloat16, attn=True)          # bf16 storage: damped residual gains (see _make)
     mb.train()
     refb = R.encoder_attn_forward(pb, x, 101, train=True)

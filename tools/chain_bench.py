@@ -2,20 +2,23 @@
 residual), B=128 at 14x14, separate weights per block -- conv kernels judged the way the network runs them (cold filter
 banks, freshly written activations), not back to back on one hot problem.  `python tools/chain_bench.py [variant ...]`:
 variant 0 = round-1 route (implicit-GEMM conv2 behind a bn_act pass), 1 = image-resident conv2 with bn1 + ReLU in its fill
-(st_conv3x3_img).  Run under `rocprofv3 --kernel-trace --stats` for per-kernel averages."""
+(st_conv3x3_img), 2 = that plus conv3 on st_conv1x1_wreg (sums conv2's replicated statistics itself).  Run under `rocprofv3 --kernel-trace --stats` for per-kernel averages."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from showtell_amd import ops
 from showtell_amd._lib import lib
-variants = [int(a) for a in sys.argv[1:]] or [0, 1]
+variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
 B, h, dt, NL, dev = 128, 14, torch.bfloat16, 22, "cuda"
 x0 = torch.relu(torch.randn(B, h, h, 1024, device=dev)).to(dt)
 W1 = [(torch.randn(256, 1024, device=dev) / 32).to(dt) for _ in range(NL)]
 W2f = [torch.randn(256, 256, 3, 3, device=dev) / 48 for _ in range(NL)]
 W2 = [ops.pack_conv_weight(w, dt, k_order=1) for w in W2f]
 W2i = [ops.pack_conv_weight_frag(w, ops.conv3x3_img_supported(h, h, 256, 256)) for w in W2f]
-W3 = [(torch.randn(1024, 256, device=dev) / 16).to(dt) for _ in range(NL)]
+W3f = [torch.randn(1024, 256, 1, 1, device=dev) / 16 for _ in range(NL)]
+W3 = [w.reshape(1024, 256).to(dt) for w in W3f]
+W3i = [ops.pack_conv_weight_frag(w, ops.conv1x1_wreg_supported(256, 1024)) for w in W3f]
+s3r = torch.zeros(4, 2048, device=dev)
 g256, b256 = torch.ones(256, device=dev), torch.zeros(256, device=dev)
 g1k, b1k = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
 n = float(B * h * h)
@@ -33,8 +36,13 @@ def fwd(variant):
             ops.conv_nhwc(y1, W2[l], 3, 3, 1, 1, stats=s2, out=y2, k_order=1)
         else:
             ops.conv3x3_img(y1, W2i[l], 256, stats=s2r, stats_replicas=16, out=y2, in_bn=dict(stats=s1, gamma=g256, beta=b256, count=n))
-            torch.sum(s2r, 0, out=s2)          # the engine's bn_reduce_replicas launch
-        ops.conv_nhwc(y2, W3[l], 1, 1, 1, 0, stats=s3, out=y3, in_bn=dict(stats=s2, gamma=g256, beta=b256, count=n))
+            if variant == 1:
+                torch.sum(s2r, 0, out=s2)      # the engine's bn_reduce_replicas launch
+        if variant == 2:
+            ops.conv1x1_wreg(y2, W3i[l], 1024, stats=s3r, stats_replicas=4, out=y3, in_bn=dict(stats=s2r, gamma=g256, beta=b256, count=n, replicas=16))
+            torch.sum(s3r, 0, out=s3)
+        else:
+            ops.conv_nhwc(y2, W3[l], 1, 1, 1, 0, stats=s3, out=y3, in_bn=dict(stats=s2, gamma=g256, beta=b256, count=n))
         ops.bn_act(y3, g1k, b1k, stats=s3, count=n, relu=True, res=x, out=y3)
         x = y3
 
