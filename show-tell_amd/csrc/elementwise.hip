@@ -114,12 +114,22 @@ template <int N> __device__ __forceinline__ void ldf(const float* p, float* f) {
     f[i] = v[0]; f[i + 1] = v[1]; f[i + 2] = v[2]; f[i + 3] = v[3];
   }
 }
-template <int N> __device__ __forceinline__ void bn_coeff_vec(const float* stats, const float* gamma, const float* beta,
+template <int N> __device__ __forceinline__ void bn_coeff_vec(const float* stats, int reps, const float* gamma, const float* beta,
                                                                const float* rmean, const float* rvar, int C, int c,
                                                                float inv_count, float eps, float* sc, float* sh) {
   float a[N], b[N], g[N], be[N];
   ldf<N>(stats ? stats + c : rmean + c, a);
   ldf<N>(stats ? stats + C + c : rvar + c, b);
+  if (stats) {   // replicated statistics ([reps][2C], st_conv_desc.stats_replicas): summed here -- a thread reads 2 x 32 bytes per
+                 // replica for its own channels, cheaper than a reduction launch in front of every normalise pass
+    for (int r = 1; r < reps; ++r) {
+      float a2[N], b2[N];
+      ldf<N>(stats + (size_t)r * 2 * C + c, a2);
+      ldf<N>(stats + (size_t)r * 2 * C + C + c, b2);
+#pragma unroll
+      for (int k = 0; k < N; ++k) { a[k] += a2[k]; b[k] += b2[k]; }
+    }
+  }
   ldf<N>(gamma + c, g);
   ldf<N>(beta + c, be);
 #pragma unroll
@@ -146,8 +156,8 @@ __global__ __launch_bounds__(256) void bn_act_reg_kernel(st_bn_act_desc d) {
   float v[N], rv[N];
   if (i < nchunk) { Vec<T>::load(x + i * N, v); if (r) Vec<T>::load(r + i * N, rv); }
   float sc[N], sh[N], rsc[N], rsh[N];
-  bn_coeff_vec<N>(d.stats, d.gamma, d.beta, d.running_mean, d.running_var, C, c, inv, d.eps, sc, sh);
-  if (d.res_bn) bn_coeff_vec<N>(d.res_stats, d.res_gamma, d.res_beta, d.res_running_mean, d.res_running_var, C, c, inv, d.eps, rsc, rsh);
+  bn_coeff_vec<N>(d.stats, d.stats_replicas, d.gamma, d.beta, d.running_mean, d.running_var, C, c, inv, d.eps, sc, sh);
+  if (d.res_bn) bn_coeff_vec<N>(d.res_stats, d.res_stats_replicas, d.res_gamma, d.res_beta, d.res_running_mean, d.res_running_var, C, c, inv, d.eps, rsc, rsh);
   for (; i < nchunk; i += stride) {
     float nv[N], nrv[N];
     const long nx = i + stride;
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
   const int cv = C / N;
   const long total = (long)B * Ho * Wo * cv;
   float sc[N], sh[N];
-  if (bn.on) bn_coeff_vec<N>(bn.stats, bn.gamma, bn.beta, bn.rmean, bn.rvar, C, (int)((threadIdx.x * N) % C), bn.inv_count, bn.eps, sc, sh);
+  if (bn.on) bn_coeff_vec<N>(bn.stats, 1, bn.gamma, bn.beta, bn.rmean, bn.rvar, C, (int)((threadIdx.x * N) % C), bn.inv_count, bn.eps, sc, sh);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv) * N;
     long p = i / cv;
@@ -451,7 +461,7 @@ extern "C" int st_bn_act(const st_bn_act_desc* d, void* stream) {
   const size_t lds = (size_t)(d->res_bn ? 4 : 2) * d->C * sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   ST_CHECK(d->stats_replicas >= 0 && d->res_stats_replicas >= 0, "st_bn_act: bad replica count");
-  const bool reg = d->stats_replicas <= 1 && d->res_stats_replicas <= 1 && (256 * n) % d->C == 0;
+  const bool reg = d->stats_replicas <= 16 && d->res_stats_replicas <= 16 && (256 * n) % d->C == 0;
   if (reg) {
     if (d->dtype == ST_BF16) hipLaunchKernelGGL(bn_act_reg_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, *d);
     else hipLaunchKernelGGL(bn_act_reg_kernel<float>, dim3(grid), dim3(256), 0, st, *d);

@@ -264,9 +264,10 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
 
   // conv: train -> raw output + statistics; eval -> folded BN (+residual)(+ReLU) in the epilogue
   // in_ci >= 0 (train): x is the RAW output of conv in_ci; this conv reads relu(bn_{in_ci}(x)) in its loader
-  // keep_rep: the consumer of this layer's statistics sums the replicas itself (conv_img.hip kernels): no reduction launch
+  // keep_rep: the consumer of this layer's statistics sums the replicas itself (everything but st_conv's input transform and
+  // the stem's pool): no reduction launch
   auto conv = [&](int ci, const void* x, int hin, int win, void* y, const void* eval_res, int eval_relu,
-                  int* ho, int* wo, int in_ci = -1, bool keep_rep = false) -> int {
+                  int* ho, int* wo, int in_ci = -1, bool keep_rep = true) -> int {
     const ConvL& c = r->convs[ci];
     st_conv_desc d;
     memset(&d, 0, sizeof(d));
@@ -335,7 +336,9 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       }
       if (st_conv3x3_img(&g, stream)) return 1;
     } else if (st_conv(&d, stream)) return 1;
-    if (train && tab.rep[ci] > 1 && !keep_rep) {
+    // every consumer of a layer's statistics sums up to 16 replicas itself (bn_act's register-coefficient kernel, the
+    // conv_img.hip loaders, the running-buffer update); only st_conv's input transform and the stem's pool read replica 0
+    if (train && tab.rep[ci] > 1 && !(keep_rep && tab.rep[ci] <= 16)) {
       const int c2 = 2 * c.cout;
       hipLaunchKernelGGL(bn_reduce_replicas_kernel, dim3((c2 + 255) / 256), dim3(256), 0, st, stats + tab.soff[ci], tab.rep[ci], c2);
       ST_LAUNCH_CHECK();
@@ -359,7 +362,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   };
 
   int h, w;
-  if (conv(0, in8, H, W, stem, nullptr, 1, &h, &w)) return 1;
+  if (conv(0, in8, H, W, stem, nullptr, 1, &h, &w, -1, false)) return 1;
   if (train) {   // bn1 + relu folded into the pool: the 64-channel 112x112 map is read once instead of three times
     const ConvL& c0 = r->convs[0];
     if (st_maxpool3x3s2_bn(stem, wide[0], dt, B, h, w, 64, stats + tab.soff[0], bn_gamma + c0.bnoff, bn_beta + c0.bnoff,
@@ -378,9 +381,10 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       const ConvL& c3 = r->convs[b.c3];
       const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h, w, c2.cin, c2.cout) == c2.ntw;   // conv1 keeps the map size
       const bool c3_sums = train && use_img && c3.ntw > 0;       // conv3 on st_conv1x1_wreg: sums conv2's replicated statistics itself
-      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1, -1, fuse1)) return 1;
+      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
       if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
-      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, fuse1 ? b.c1 : -1, c3_sums)) return 1;
+      const bool fuse2_ = train && c3.cin % 64 == 0;              // conv3 applies bn2 + relu in its loader
+      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, fuse1 ? b.c1 : -1, c3_sums || !fuse2_)) return 1;
       // train: bn2 + relu are applied by conv3's loader (no separate pass over the 3x3 output); needs whole 64-channel
       // (f32: 32) K tiles, which every bottleneck width satisfies
       const bool fuse2 = train && r->convs[b.c3].cin % 64 == 0;
@@ -397,7 +401,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       const ConvL& c2 = r->convs[b.c2];
       const int h1p = conv_out(h, c1.k, c1.stride, c1.pad), w1p = conv_out(w, c1.k, c1.stride, c1.pad);
       const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h1p, w1p, c2.cin, c2.cout) == c2.ntw;
-      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1, -1, fuse1)) return 1;
+      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
       if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       const void* res = xin;
       if (b.ds >= 0) {
