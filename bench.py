@@ -413,15 +413,14 @@ def main():
                 r32, r16 = r32.to(dev).eval(), r16.to(dev).eval()
                 f32_ = torch.randn(32, E, device=dev)
                 boost_used, h32 = None, None
-                for boost in (0.2, 0.3, 0.4, 0.5, 0.65, 0.8):      # the smallest <end> bias that completes most captions with >= 6 tokens
+                for boost in (0.2, 0.3, 0.4, 0.5, 0.65, 0.8):      # the smallest <end> bias that lets most captions complete within 25 steps
                     sd_b = dict(sd_); sd_b["linear.bias"] = sd_["linear.bias"].clone(); sd_b["linear.bias"][2] += boost
                     r32.load_state_dict(sd_b)
                     h = r32.beam_search(f32_, 5, 1, 25)
                     done = [len(x[0][0]) for x in h if x]
-                    if len(done) >= 24:
+                    if len(done) >= 24:                             # first (= longest-caption) setting that completes 3/4 of the images
                         boost_used, h32 = boost, h
-                        if sum(done) / len(done) >= 6:
-                            break
+                        break
                 if h32 is None:
                     boost_used, h32 = boost, h
                 sd_b = dict(sd_); sd_b["linear.bias"] = sd_["linear.bias"].clone(); sd_b["linear.bias"][2] += boost_used

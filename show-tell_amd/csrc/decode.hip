@@ -445,7 +445,9 @@ extern "C" size_t st_rnn_greedy_workspace_bytes(const st_rnn_params* p, int B) {
   if (!p || B <= 0) return 0;
   const size_t es = st_dtype_size(p->dtype);
   const size_t hb = al((size_t)p->L * B * p->H * es);
-  return 4 * hb + al((size_t)B * p->E * es) + al((size_t)B * up8(p->V) * sizeof(float)) + al((size_t)B * kFusedSteps * sizeof(unsigned long long));
+  const int ng = p->cell == ST_CELL_GRU ? 3 : 4;
+  return 4 * hb + al((size_t)B * p->E * es) + al((size_t)B * up8(p->V) * sizeof(float)) + al((size_t)B * kFusedSteps * sizeof(unsigned long long)) +
+         al((size_t)p->L * B * ng * p->H * sizeof(float));       // recurrent halves of the split step (gh)
 }
 
 extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, int steps, void* workspace, size_t workspace_bytes,
@@ -469,8 +471,57 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
   if (!logits_out && hipMemsetAsync(keys, 0, (size_t)B * (fused ? steps : 1) * sizeof(unsigned long long), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
   const void* x = feat;
   int cur = 0;
+  // Split step (greedy fast path; ST_DECODE_SPLIT=0 restores the fused cells): the recurrent half W_hh h_l(t) + b_hh of layer l
+  // is NOT on the token -> token chain once h_l(t) exists, so it is computed as extra blocks of the NEXT launch on the stream
+  // (cell l+1 of the same step; layer L-1's rides with cell 0 of the next step) and handed over as fp32 `gh`; the cells on the
+  // chain multiply only the input half (x, W_ih): half the operand bytes and MFMAs per dependent launch.
+  static const bool split_env = [] { const char* e = getenv("ST_DECODE_SPLIT"); return !e || atoi(e) != 0; }();
+  const int NGc = p->cell == ST_CELL_GRU ? 3 : 4;
+  float* gh = reinterpret_cast<float*>(reinterpret_cast<char*>(keys) + al((size_t)B * kFusedSteps * sizeof(unsigned long long)));
+  const size_t gh_l = (size_t)B * NGc * H;
+  const bool split = fused && split_env && L >= 2;
+  auto gh_cell = [&](int l, const void* hsrc) {          // gh[l] = W_hh[l] hsrc + b_hh[l]  (hsrc == NULL: the bias alone, h = 0)
+    RnnGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = B; g.N = H; g.gstride = H;
+    g.A = hsrc; g.W = p->w_hh[l]; g.K = H; g.lda = H; g.ldw = H;
+    g.bias_h = p->b_hh[l]; g.accumulate = kCellRawOut; g.out_f32 = gh + (size_t)l * gh_l; g.ldo = NGc * H;
+    return g;
+  };
+  if (split) {                                           // step 0: h(-1) = 0 -> gh = b_hh for every layer, one launch
+    RnnGemmArgs cells[ST_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) cells[l] = gh_cell(l, nullptr);
+    if (rnn_gemm_launch_batch(cells, L, dt, p->cell == ST_CELL_GRU ? 1 : 2, 0, st)) return 1;
+  }
   for (int t = 0; t < steps; ++t) {
     const int nxt = cur ^ 1;
+    if (split) {
+      for (int l = 0; l < L; ++l) {
+        RnnGemmArgs c2[2];
+        RnnGemmArgs& a = c2[0];
+        memset(&a, 0, sizeof(a));
+        a.M = B; a.N = H; a.gstride = H;
+        a.A = l == 0 ? x : hbuf[nxt] + (size_t)(l - 1) * B * H * es;         // input half on the MFMA operand pair
+        a.W = p->w_ih[l]; a.K = l == 0 ? E : H; a.lda = a.K; a.ldw = a.K;
+        if (l == 0 && t > 0) {                            // embedding rows of step t-1's tokens, gathered by the cell
+          a.A = p->emb; a.x_keys = keys + (size_t)(t - 1) * B; a.x_V = V;
+          a.ids_out = ids_out; a.ids_stride = steps; a.ids_t = t - 1;
+        }
+        a.bias_h = p->b_ih[l];
+        a.accumulate = kCellSplit; a.gx = gh + (size_t)l * gh_l; a.ldgx = NGc * H;
+        a.hprev = t > 0 ? hbuf[cur] + (size_t)l * B * H * es : nullptr; a.ldhp = H;
+        a.hout = hbuf[nxt] + (size_t)l * B * H * es; a.ldho = H;
+        if (p->cell == ST_CELL_LSTM) {
+          a.cprev = t > 0 ? cbuf[cur] + (size_t)l * B * H * es : nullptr;
+          a.cout = cbuf[nxt] + (size_t)l * B * H * es;
+        }
+        int n = 1;
+        // riding along: the recurrent half some LATER cell needs, from a state that is already complete
+        if (l == 0) { if (t > 0) c2[n++] = gh_cell(L - 1, hbuf[cur] + (size_t)(L - 1) * B * H * es); }   // h_{L-1}(t-1) -> cell L-1 of THIS step
+        else if (t + 1 < steps) c2[n++] = gh_cell(l - 1, hbuf[nxt] + (size_t)(l - 2 + 1) * B * H * es);   // h_{l-1}(t) -> cell l-1 of step t+1
+        if (rnn_gemm_launch_batch(c2, n, dt, p->cell == ST_CELL_GRU ? 1 : 2, 0, st)) return 1;
+      }
+    } else
     for (int l = 0; l < L; ++l) {
       RnnGemmArgs a;
       memset(&a, 0, sizeof(a));

@@ -123,6 +123,7 @@ extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
     // the stride-2 512-channel downsample stays with st_conv (measured slower there)
     if (dtype == ST_BF16 && k == 1 && p == 0 && !(s == 2 && cin == 512)) {
       c.ntw = st_conv1x1_wreg_supported(cin, cout);
+      if (c.ntw == 0) c.ntw = st_conv1x1_kstream_supported(cin, cout);     // 1024 / 2048 input channels: the K-streaming kernel
       if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * cin; }
     }
     r->bntotal += cout;
@@ -316,7 +317,10 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
       }
-      if (st_conv1x1_wreg(&g, stream)) return 1;
+      if (c.cin > 512) {
+        ST_CHECK(!g.in_stats, "st_resnet_forward: the long-K pointwise kernel has no input transform");
+        if (st_conv1x1_kstream(&g, stream)) return 1;
+      } else if (st_conv1x1_wreg(&g, stream)) return 1;
     } else if (c.ntw > 0 && c.k == 3 && use_img && !d.residual && st_conv3x3_img_supported(hin, win, c.cin, c.cout) == c.ntw) {
       // image-resident 3x3 (conv_img.hip): the producer's BatchNorm + ReLU ride in its fill, replicated statistics in and out
       st_conv3x3_img_desc g;

@@ -20,7 +20,14 @@ struct RnnGemmArgs {
   // embedding gather of the previous step's arg-max happens inside the cell; block column 0 also writes the token ids
   const unsigned long long* x_keys; int x_V;
   long* ids_out; int ids_stride, ids_t;
+  // split decode step (HAS_X = false forms of EPI 1 / 2): the recurrent half W_hh h + b_hh of a cell is produced OFF the
+  // critical chain one launch earlier (raw_out cell: the NG gate sums + bias_h go to out_f32[m][g * N + n], fp32) and handed to
+  // the cell as `gh`; the cell's MFMA operand pair (A, W) is then the INPUT half (x, W_ih), bias_h = b_ih, and x_keys gathers
+  // the rows of A.  Half the operand bytes and MFMAs per launch on the chain.
+  // No new fields (16 cells must fit the 4 KiB kernel-argument segment): in these forms `accumulate` carries the mode
+  // (kCellRawOut / kCellSplit) and (gx, ldgx) point at the fp32 gh rows.
 };
+constexpr int kCellRawOut = 1, kCellSplit = 2;
 
 // Up to kRnnBatch independent cells in ONE launch (blockIdx.z picks the cell): the (layer, time) wavefront of the
 // teacher-forced decoder, where the cells of a diagonal layer + time = d do not depend on each other.

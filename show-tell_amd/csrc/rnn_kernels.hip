@@ -84,6 +84,15 @@ __device__ __forceinline__ void skinny_mma(const RnnGemmArgs& a, int mbase, int 
     const int m = mbase + t * 16 + r16;
     mok[t] = m < a.M;
     AH[t] = reinterpret_cast<const T*>(a.A) + (long)m * a.lda;
+    if (!HAS_X && a.x_keys && a.A) {                   // split decode step: the A operand is the embedding row of the previous token
+      int tok = 0;
+      if (mok[t]) {
+        tok = (int)(0xffffffffu - (unsigned)(a.x_keys[m] & 0xffffffffull));
+        if (tok < 0 || tok >= a.x_V) tok = 0;
+        if (a.ids_out && n0 == 0 && kslice == 0 && q4 == 0) a.ids_out[(long)m * a.ids_stride + a.ids_t] = tok;
+      }
+      AH[t] = reinterpret_cast<const T*>(a.A) + (long)tok * a.lda;
+    }
     long xrow = m;
     if (HAS_X && a.x_keys) {                           // token of the previous step -> embedding row
       int tok = 0;
@@ -182,10 +191,11 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
       for (int g = 0; g < NG; ++g) {
         load4<float>(a.bias_h + g * a.N + pn, eb[g]);
         if (HAS_X) load4<float>(a.bias_x + g * a.N + pn, ex[g]);
-        else load4<T>(reinterpret_cast<const T*>(a.gx) + (long)pm * a.ldgx + g * a.N + pn, ex[g]);   // already holds b_ih
+        else if (a.accumulate == kCellSplit) load4<float>(reinterpret_cast<const float*>(a.gx) + (long)pm * a.ldgx + g * a.N + pn, ex[g]);   // recurrent half, already holds b_hh
+        else if (a.accumulate != kCellRawOut) load4<T>(reinterpret_cast<const T*>(a.gx) + (long)pm * a.ldgx + g * a.N + pn, ex[g]);   // already holds b_ih
       }
       const void* prev = EPI == 1 ? a.hprev : a.cprev;
-      if (prev) load4<T>(reinterpret_cast<const T*>(prev) + (long)pm * a.ldhp + pn, es);
+      if (prev && a.accumulate != kCellRawOut) load4<T>(reinterpret_cast<const T*>(prev) + (long)pm * a.ldhp + pn, es);
     }
   }
   skinny_mma<T, NG, HAS_X, MT>(a, mbase, n0, r16, q4, wid, accH, accX);
@@ -240,19 +250,26 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
     for (int e = 0; e < 4; ++e) v[e] = sumH[0][e] + eb[0][e] + es[e];
     if (a.hout) store4<T>(reinterpret_cast<T*>(a.hout) + (long)m * a.ldho + n, v);      // output in the storage type (ldho)
     else *reinterpret_cast<f32x4*>(a.out_f32 + (long)m * a.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
+  } else if (!HAS_X && a.accumulate == kCellRawOut) {
+    // recurrent half for the NEXT use of this layer's cell: gate sums + b_hh, fp32, [m][g * N + n]
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      *reinterpret_cast<f32x4*>(a.out_f32 + (long)m * a.ldo + g * a.N + n) =
+          f32x4{sumH[g][0] + eb[g][0], sumH[g][1] + eb[g][1], sumH[g][2] + eb[g][2], sumH[g][3] + eb[g][3]};
   } else if (EPI == 1) {
     // r,z,n order (torch.nn.GRU): r = s(xr+hr), z = s(xz+hz), n = tanh(xn + r*(hn)), h' = (1-z) n + z h
     float xg[3][4];
     const float* hp = es;
+    const bool split = !HAS_X && a.accumulate == kCellSplit;   // MFMA sums = input half (+ b_ih in eb), ex = recurrent half (+ b_hh)
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xg[g][e] = (HAS_X ? sumX[g][e] : 0.f) + ex[g][e];
+      for (int e = 0; e < 4; ++e) xg[g][e] = split ? sumH[g][e] + eb[g][e] : (HAS_X ? sumX[g][e] : 0.f) + ex[g][e];
     float hn[4], r[4], z[4], nn[4], hnew[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float hr = sumH[0][e] + eb[0][e], hz = sumH[1][e] + eb[1][e];
-      hn[e] = sumH[2][e] + eb[2][e];
+      const float hr = split ? ex[0][e] : sumH[0][e] + eb[0][e], hz = split ? ex[1][e] : sumH[1][e] + eb[1][e];
+      hn[e] = split ? ex[2][e] : sumH[2][e] + eb[2][e];
       r[e] = sigm(xg[0][e] + hr);
       z[e] = sigm(xg[1][e] + hz);
       nn[e] = tanhf(xg[2][e] + r[e] * hn[e]);

@@ -263,6 +263,23 @@ def conv1x1_wreg(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=Non
     return out
 
 
+def conv1x1_kstream_supported(Cin, N):
+    return int(lib().st_conv1x1_kstream_supported(Cin, N))
+
+
+def conv1x1_kstream(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, out=None):
+    """Long-K 1x1 conv (st_conv1x1_kstream): x (B,H,W,C) bf16 NHWC with C in {1024, 2048}, w_frag = pack_conv_weight_frag(w, 4)."""
+    _dev(x, w_frag, stats, scale, shift, out)
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, N, device=x.device, dtype=torch.bfloat16)
+    d = Conv1x1WregDesc(_p(x), _p(w_frag), _p(out), None, _p(stats), int(stats_replicas), _p(scale), _p(shift), int(relu),
+                        None, None, None, 0.0, 0.0, 0, B, H, W, Cc, N, int(stride))
+    check(lib().st_conv1x1_kstream(C.byref(d), _stream()), "st_conv1x1_kstream")
+    return out
+
+
 def pack_conv_weight(w, dtype, cpad=None, k_order=0):
     """(Cout,Cin,KH,KW) fp32 torch layout -> (Cout, KH*KW*Cpad) K-contiguous (k_order: see st_conv_desc)."""
     _dev(w)

@@ -190,3 +190,45 @@ def test_conv1x1_wreg_fused_input_bn_relu_and_eval_epilogue(case):
     from showtell_amd import ShowTellHipError
     with pytest.raises(ShowTellHipError):
         ops.conv1x1_wreg(xd, wf, N, stride=s, residual=y)
+
+
+# ---- st_conv1x1_kstream: (B, H, W, C, N, stride) ---------------------------------------------------------------------
+KS_CASES = [
+    (4, 14, 14, 1024, 256, 1),    # layer3 conv1
+    (3, 14, 14, 1024, 512, 1),    # layer4 conv1 of block 0 (two channel slices)
+    (5, 7, 7, 2048, 512, 1),      # layer4 conv1, ragged rows (245 = 2 x 112 + 21)
+    (3, 14, 14, 1024, 2048, 2),   # layer4 downsample (stride 2)
+    (1, 3, 5, 1024, 256, 1),      # fewer rows than one tile
+]
+
+
+@pytest.mark.parametrize("case", KS_CASES)
+def test_conv1x1_kstream_matches_conv2d_and_igemm(case):
+    ops = _ops()
+    B, H, W, C, N, s = case
+    assert ops.conv1x1_kstream_supported(C, N) == 4 and ops.conv1x1_kstream_supported(512, 256) == 0
+    x, w = _pw_data(case)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, s, 0).permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda()
+    wf = ops.pack_conv_weight_frag(w.cuda(), 4)
+    R = 4
+    st = torch.zeros(R, 2 * N, device="cuda")
+    y = ops.conv1x1_kstream(xd, wf, N, stride=s, stats=st, stats_replicas=R)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert y.shape == ref.shape
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * scale
+    s0 = torch.zeros(2 * N, device="cuda")
+    y0 = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16), 1, 1, s, 0, stats=s0)
+    assert (y.float() - y0.float()).abs().max().item() <= 2.0 ** -7 * scale
+    assert (y != y0).float().mean().item() < 0.02
+    r2 = ref.reshape(-1, N)
+    tot = st.sum(0).cpu().numpy()
+    np.testing.assert_allclose(tot[:N], r2.sum(0).numpy(), rtol=2e-3, atol=2e-3 * scale * np.sqrt(r2.shape[0]))
+    np.testing.assert_allclose(tot[N:], (r2 * r2).sum(0).numpy(), rtol=2e-3)
+    # eval-mode epilogue
+    g = torch.Generator().manual_seed(4)
+    sc, sh = (torch.rand(N, generator=g) + 0.5), torch.randn(N, generator=g) * 0.3
+    y2 = ops.conv1x1_kstream(xd, wf, N, stride=s, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    ref2 = F.relu(ref * sc + sh)
+    assert (y2.float().cpu() - ref2).abs().max().item() <= 1.5e-2 * ref2.abs().max().item()
