@@ -127,6 +127,11 @@ int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream);
  * (fragment-major filters, ntw = 4).  Same descriptor; in_stats and residual must be NULL. */
 int st_conv1x1_kstream_supported(int C, int N);
 int st_conv1x1_kstream(const st_conv1x1_wreg_desc* d, void* stream);
+/* The activation-stationary sibling for (C, N) = (256, 1024) / (512, 2048) (conv3 of the layer3 / layer4 Bottlenecks): a
+ * workgroup keeps its 112 x C rows in LDS (producer's BatchNorm + ReLU applied once per element) and walks all N output
+ * channels barrier-free.  Same descriptor (ntw = 4 weights), stride 1, residual NULL. */
+int st_conv1x1_astat_supported(int C, int N);
+int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream);
 
 /* [Cout][Cin][KH][KW] fp32 (torch layout) -> fragment-major bf16: element ((T * KS + ks) * 64 + lane) * 8 + j is
  * w[ch(T, lane & 15)][k = 32 ks + 8 (lane >> 4) + j] with k = (kh * KW + kw) * Cin + c and
@@ -136,7 +141,7 @@ int st_pack_conv_weight_frag(const float* w, void* out, int Cout, int Cin, int K
 
 /* Launch profiler for bench.py's roofline: HIP events around every convolution launch on its stream.
  * st_prof_collect fills 16-entry arrays indexed by kernel variant (0: bf16 128x128 tile family,
- * 1: bf16 128x64, 2: bf16 64x128, 3: 256x128, 4..7 the same for f32, 8: st_conv3x3_img, 9: st_conv1x1_wreg, 10: st_conv1x1_kstream; csrc/prof.h); synchronise the device first. */
+ * 1: bf16 128x64, 2: bf16 64x128, 3: 256x128, 4..7 the same for f32, 8: st_conv3x3_img, 9: st_conv1x1_wreg, 10: st_conv1x1_kstream, 11: st_conv1x1_astat; csrc/prof.h); synchronise the device first. */
 int st_tune(int reserved, int kc, int w8);   /* main-loop variant knobs for tools/bench_conv.py (row chunk count 4|8, block shape); -1 = keep */
 int st_prof_enable(int on);
 /* debug aid: per-block phase timestamps of st_conv launches (tools/conv_stamps.py); NULL = off (default) */

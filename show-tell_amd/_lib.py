@@ -88,6 +88,8 @@ _SIGS = {
     "st_conv3x3_img": ([C.POINTER(Conv3x3ImgDesc), c_p], c_i),
     "st_conv1x1_wreg_supported": ([c_i, c_i], c_i),
     "st_conv1x1_wreg": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
+    "st_conv1x1_astat_supported": ([c_i, c_i], c_i),
+    "st_conv1x1_astat": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_conv1x1_kstream_supported": ([c_i, c_i], c_i),
     "st_conv1x1_kstream": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_pack_conv_weight_frag": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),

@@ -630,6 +630,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef KS_STAMP
 }
 
+// =====================================================================================================================
+// Pointwise convolution, activation-stationary: K = 256 / 512 input channels, N a multiple of 256 output channels (the
+// conv3 of the layer3 / layer4 Bottlenecks, 256 -> 1024 and 512 -> 2048; reference cnn.py:46).  A workgroup owns 112 rows:
+//   * its 112 x K activation block is read ONCE, normalised on the way in (producer's BatchNorm + ReLU -- once per element,
+//     not once per output-channel slice as in conv1x1_wreg_kernel) and stays in LDS (padded rows);
+//   * the workgroup then walks ALL output channels in chunks of 256 (64 per wave) with NO barrier: filters stream
+//     fragment-major through the 6-K-step register ring across chunk boundaries, the chunk's epilogue (stores straight from
+//     the accumulators) sits in the same straight-line stream as the next chunk's MFMAs;
+//   * per-channel statistics of every chunk are parked in LDS and leave as full-wave atomics once, at the end.
+struct AsArgs {
+  const bf16_t* x; const bf16_t* w; bf16_t* y;
+  float* stats; int srep;
+  const float* scale; const float* shift; int relu;
+  const float* in_stats; const float* in_gamma; const float* in_beta; float in_count, in_eps; int in_srep;
+  int M, N;
+  unsigned long long* stamps;   // debug (tools/as_stamps.py), normally NULL
+};
+
+template <int K, int NCH, bool AFFINE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_astat_kernel(AsArgs a) {
+  constexpr int TM = 7, NTW = 4, BM = 16 * TM;
+  constexpr int PIX = 2 * K + 32, KS = K / 32, CH8 = K / 8;
+  constexpr int RPP = 256 / CH8, NL = BM / RPP;                      // rows per loader pass, loads per thread
+  constexpr int WR = 6;
+  constexpr int TOT = NCH * KS;                                      // K-steps over the whole channel walk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sstat = reinterpret_cast<float*>(smem + BM * PIX);          // [2][256 NCH] statistics of every chunk
+  float* coef = sstat + 2 * 256 * NCH;                               // [2][K] producer's scale / shift
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bm;
+  {
+    const int nblk = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    bm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const u32x4* wl = reinterpret_cast<const u32x4*>(a.w) + lane;
+  // K-step g of the walk: chunk g / KS, k-step g % KS, this wave's tiles (chunk * 4 + wid) * 4 + j
+  auto wfrag = [&](int g, int j) { return wl[((size_t)(((g / KS) * 4 + wid) * NTW + j) * KS + g % KS) * 64]; };
+#define AS_STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  AS_STAMP(0);
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  u32x4 wq[WR][NTW];
+#pragma unroll
+  for (int g = 0; g < WR; ++g)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wq[g][j] = wfrag(g, j);
+
+  // ---- fill: 112 rows x K, every load in flight before the first LDS write -------------------------------------------
+  {
+    const int cch = tid % CH8, lrow = tid / CH8;
+    u32x4 v[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int m = bm * BM + lrow + i * RPP;
+      m = m < a.M ? m : a.M - 1;
+      v[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)m * K + cch * 8);
+    }
+    if (a.in_stats) {
+      const float inv = 1.0f / a.in_count;
+      for (int c = tid; c < K; c += 256) {
+        float sm = 0.f, sq = 0.f;
+        for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * K + c]; sq += a.in_stats[(size_t)r * 2 * K + K + c]; }
+        const float mean = sm * inv;
+        const float var = fmaxf(sq * inv - mean * mean, 0.f);
+        const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
+        coef[c] = scv; coef[K + c] = a.in_beta[c] - mean * scv;
+      }
+      __syncthreads();
+      float sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = coef[cch * 8 + e]; sh[e] = coef[K + cch * 8 + e]; }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) bn_relu_chunk(v[i], sc, sh);
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<u32x4*>(smem + (lrow + i * RPP) * PIX + cch * 16) = v[i];
+  }
+  __syncthreads();
+  AS_STAMP(1);
+
+  // ---- channel walk: no barrier from here to the statistics flush -------------------------------------------------------
+  constexpr int NC = 4 * NTW;
+  const char* abase = smem + r16 * PIX + q4 * 16;
+  auto read_a = [&](u32x4 (&f)[TM], int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f[i] = *reinterpret_cast<const u32x4*>(abase + i * 16 * PIX + ks * 64);
+  };
+  u32x4 fa0[TM], fa1[TM];
+  read_a(fa0, 0);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    f32x4 acc[TM][NTW];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int g = ch * KS + ks;
+      u32x4 (&fa)[TM] = (g & 1) ? fa1 : fa0;
+      u32x4 (&fn)[TM] = (g & 1) ? fa0 : fa1;
+      if (g + 1 < TOT) read_a(fn, (ks + 1) % KS);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = mfma_bf16(wq[g % WR][j], fa[i], acc[i][j]);
+      if (g + WR < TOT) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) wq[g % WR][j] = wfrag(g + WR, j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // chunk epilogue
+    const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;              // this lane's 16 consecutive channels
+    float es[NC], ess[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = bm * BM + i * 16 + r16;
+      if (m < a.M) {
+        float v[NC];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
+        if constexpr (AFFINE) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) v[c] = v[c] * a.scale[cb + c] + a.shift[cb + c];
+          if (a.relu) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
+          }
+        }
+        bf16_t* dst = a.y + (size_t)m * a.N + cb;
+#pragma unroll
+        for (int h = 0; h < NTW / 2; ++h)
+          *reinterpret_cast<u32x4*>(dst + 8 * h) = u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                                         pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
+      if (r16 == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { sstat[cb + c] = es[c]; sstat[256 * NCH + cb + c] = ess[c]; }
+      }
+    }
+    if (ch == 0) AS_STAMP(2);
+    if (ch == NCH / 2 - 1) AS_STAMP(3);
+    if (ch == NCH - 1) AS_STAMP(4);
+  }
+  if (a.stats) {
+    float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);
+    __syncthreads();
+    for (int t = tid; t < 2 * 256 * NCH; t += 256) atomicAdd(sdst + t, sstat[t]);   // [sum(N) | sumsq(N)] is exactly sstat's layout (N = 256 NCH)
+  }
+  AS_STAMP(5);
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#undef AS_STAMP
+}
+
 // ---- fragment-major filter bank ---------------------------------------------------------------------------------
 // out[((T * KS + ks) * 64 + lane) * 8 + j], T = 16-channel tile, ks = 32-deep K step (k = tap * Cin + c), lane = (q4, r16):
 // MFMA row r16 of tile T is output channel ch(T, r16) = (T / NTW) * 16 NTW + 4 NTW (r16 / 4) + 4 (T % NTW) + r16 % 4
@@ -849,6 +1016,51 @@ int launch_ks(KsArgs& a, hipStream_t st, double flops) {
   return a.scale ? launch_ks_<K, false, true>(a, st, flops) : launch_ks_<K, false, false>(a, st, flops);
 }
 }  // namespace
+
+namespace {
+template <int K, int NCH, bool AFFINE>
+int launch_as_(AsArgs& a, hipStream_t st, double flops) {
+  constexpr int lds = 112 * (2 * K + 32) + 2 * 256 * NCH * 4 + 2 * K * 4;
+  static_assert(lds <= 160 * 1024, "activation block does not fit");
+  static int attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_astat_kernel<K, NCH, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[dev] = 1;
+  }
+  StProfScope prof(11, flops, st);
+  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE>), dim3((a.M + 111) / 112), dim3(256), lds, st, a);
+  prof.end(st);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
+// 4: supported (ntw of the fragment-major weights); 0: not.  (C, N) in {(256, 1024), (512, 2048)}: conv3 of layer3 / layer4.
+extern "C" int st_conv1x1_astat_supported(int K, int N) { return ((K == 256 && N == 1024) || (K == 512 && N == 2048)) ? 4 : 0; }
+
+extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
+  ST_CHECK(d && d->x && d->w_frag && d->y, "st_conv1x1_astat: null pointer");
+  ST_CHECK(st_conv1x1_astat_supported(d->C, d->N), "st_conv1x1_astat: unsupported geometry C=%d N=%d", d->C, d->N);
+  ST_CHECK(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->stride == 1, "st_conv1x1_astat: bad geometry (stride 1 only)");
+  ST_CHECK((d->scale == nullptr) == (d->shift == nullptr) && (d->scale || !d->relu), "st_conv1x1_astat: scale, shift (and relu) go together");
+  ST_CHECK(!d->residual, "st_conv1x1_astat: no residual input (use st_conv)");
+  ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f), "st_conv1x1_astat: input transform needs gamma, beta, count");
+  ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->in_stats_replicas >= 0 && d->in_stats_replicas <= 1024, "st_conv1x1_astat: bad stats_replicas");
+  AsArgs a;
+  a.x = reinterpret_cast<const bf16_t*>(d->x); a.w = reinterpret_cast<const bf16_t*>(d->w_frag); a.y = reinterpret_cast<bf16_t*>(d->y);
+  a.stats = d->stats; a.srep = d->stats_replicas; a.scale = d->scale; a.shift = d->shift; a.relu = d->relu;
+  a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_count = d->in_count; a.in_eps = d->in_eps;
+  a.in_srep = d->in_stats_replicas > 1 ? d->in_stats_replicas : 1;
+  const long M = (long)d->B * d->Hin * d->Win;
+  ST_CHECK(M < (1L << 31) - 4096, "st_conv1x1_astat: too many rows");
+  a.M = (int)M; a.N = d->N; a.stamps = st_debug_stamps_ptr();
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const double flops = 2.0 * (double)M * d->N * d->C;
+  if (d->C == 256) return a.scale ? launch_as_<256, 4, true>(a, st, flops) : launch_as_<256, 4, false>(a, st, flops);
+  return a.scale ? launch_as_<512, 8, true>(a, st, flops) : launch_as_<512, 8, false>(a, st, flops);
+}
 
 // 4: supported (the `ntw` of the fragment-major weights); 0: use st_conv
 extern "C" int st_conv1x1_kstream_supported(int K, int N) { return (K == 1024 || K == 2048) && N % 256 == 0 ? 4 : 0; }

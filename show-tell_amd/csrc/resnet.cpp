@@ -122,7 +122,8 @@ extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
     // pointwise layers with <= 512 input channels: fragment-major copy for the register-resident-filter kernel (st_conv1x1_wreg);
     // the stride-2 512-channel downsample stays with st_conv (measured slower there)
     if (dtype == ST_BF16 && k == 1 && p == 0 && !(s == 2 && cin == 512)) {
-      c.ntw = st_conv1x1_wreg_supported(cin, cout);
+      c.ntw = s == 1 ? st_conv1x1_astat_supported(cin, cout) : 0;          // conv3 of layer3 / layer4: activation-stationary kernel
+      if (c.ntw == 0) c.ntw = st_conv1x1_wreg_supported(cin, cout);
       if (c.ntw == 0) c.ntw = st_conv1x1_kstream_supported(cin, cout);     // 1024 / 2048 input channels: the K-streaming kernel
       if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * cin; }
     }
@@ -317,7 +318,9 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
       }
-      if (c.cin > 512) {
+      if (c.stride == 1 && st_conv1x1_astat_supported(c.cin, c.cout)) {
+        if (st_conv1x1_astat(&g, stream)) return 1;
+      } else if (c.cin > 512) {
         ST_CHECK(!g.in_stats, "st_resnet_forward: the long-K pointwise kernel has no input transform");
         if (st_conv1x1_kstream(&g, stream)) return 1;
       } else if (st_conv1x1_wreg(&g, stream)) return 1;

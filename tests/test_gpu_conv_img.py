@@ -232,3 +232,47 @@ def test_conv1x1_kstream_matches_conv2d_and_igemm(case):
     y2 = ops.conv1x1_kstream(xd, wf, N, stride=s, scale=sc.cuda(), shift=sh.cuda(), relu=True)
     ref2 = F.relu(ref * sc + sh)
     assert (y2.float().cpu() - ref2).abs().max().item() <= 1.5e-2 * ref2.abs().max().item()
+
+
+# ---- st_conv1x1_astat: (B, H, W, C, N) -----------------------------------------------------------------------------------
+AS_CASES = [(4, 14, 14, 256, 1024), (5, 7, 7, 512, 2048), (1, 3, 5, 256, 1024)]
+
+
+@pytest.mark.parametrize("case", AS_CASES)
+def test_conv1x1_astat_matches_conv2d_igemm_and_separate_bn_pass(case):
+    ops = _ops()
+    B, H, W, C, N = case
+    assert ops.conv1x1_astat_supported(C, N) == 4 and ops.conv1x1_astat_supported(256, 512) == 0
+    x, w = _pw_data(case + (1,))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, 0).permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda()
+    wf = ops.pack_conv_weight_frag(w.cuda(), 4)
+    R = 4
+    st = torch.zeros(R, 2 * N, device="cuda")
+    y = ops.conv1x1_astat(xd, wf, N, stats=st, stats_replicas=R)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * scale
+    s0 = torch.zeros(2 * N, device="cuda")
+    y0 = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16), 1, 1, 1, 0, stats=s0)
+    assert (y.float() - y0.float()).abs().max().item() <= 2.0 ** -7 * scale
+    assert (y != y0).float().mean().item() < 0.02
+    r2 = ref.reshape(-1, N)
+    tot = st.sum(0).cpu().numpy()
+    np.testing.assert_allclose(tot[:N], r2.sum(0).numpy(), rtol=2e-3, atol=2e-3 * scale * np.sqrt(r2.shape[0]))
+    np.testing.assert_allclose(tot[N:], (r2 * r2).sum(0).numpy(), rtol=2e-3)
+    # fused producer BatchNorm + ReLU == separate pass, bit for bit; replicated producer statistics
+    g = torch.Generator().manual_seed(11)
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    x2 = xd.float().reshape(-1, C)
+    stats = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).contiguous()
+    n = float(B * H * W)
+    y_sep = ops.conv1x1_astat(ops.bn_act(xd, gam, bet, stats=stats, count=n, relu=True), wf, N)
+    rep = torch.zeros(3, 2 * C, device="cuda"); rep[0] = stats
+    y_fused = ops.conv1x1_astat(xd, wf, N, in_bn=dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=3))
+    assert torch.equal(y_sep, y_fused)
+    # eval-mode epilogue
+    sc, sh = (torch.rand(N, generator=g) + 0.5), torch.randn(N, generator=g) * 0.3
+    y2 = ops.conv1x1_astat(xd, wf, N, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    ref2 = F.relu(ref * sc + sh)
+    assert (y2.float().cpu() - ref2).abs().max().item() <= 1.5e-2 * ref2.abs().max().item()

@@ -2,13 +2,14 @@
 residual), B=128 at 14x14, separate weights per block -- conv kernels judged the way the network runs them (cold filter
 banks, freshly written activations), not back to back on one hot problem.  `python tools/chain_bench.py [variant ...]`:
 variant 0 = round-1 route (implicit-GEMM conv2 behind a bn_act pass), 1 = image-resident conv2 with bn1 + ReLU in its fill
-(st_conv3x3_img), 2 = that plus conv3 on st_conv1x1_wreg (sums conv2's replicated statistics itself).  Run under `rocprofv3 --kernel-trace --stats` for per-kernel averages."""
+(st_conv3x3_img), 2 = that plus conv3 on st_conv1x1_wreg (sums conv2's replicated statistics itself), 3 = conv1 on st_conv1x1_kstream, conv2 image-resident,
+conv3 on st_conv1x1_astat (the round-2 route of the engine).  Run under `rocprofv3 --kernel-trace --stats` for per-kernel averages."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from showtell_amd import ops
 from showtell_amd._lib import lib
-variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
+variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3]
 B, h, dt, NL, dev = 128, 14, torch.bfloat16, 22, "cuda"
 x0 = torch.relu(torch.randn(B, h, h, 1024, device=dev)).to(dt)
 W1 = [(torch.randn(256, 1024, device=dev) / 32).to(dt) for _ in range(NL)]
@@ -18,6 +19,10 @@ W2i = [ops.pack_conv_weight_frag(w, ops.conv3x3_img_supported(h, h, 256, 256)) f
 W3f = [torch.randn(1024, 256, 1, 1, device=dev) / 16 for _ in range(NL)]
 W3 = [w.reshape(1024, 256).to(dt) for w in W3f]
 W3i = [ops.pack_conv_weight_frag(w, ops.conv1x1_wreg_supported(256, 1024)) for w in W3f]
+W3a = [ops.pack_conv_weight_frag(w, 4) for w in W3f]
+W1f = [w.float().reshape(256, 1024, 1, 1) for w in W1]
+W1k = [ops.pack_conv_weight_frag(w, 4) for w in W1f]
+s1r = torch.zeros(16, 512, device=dev)
 s3r = torch.zeros(4, 2048, device=dev)
 g256, b256 = torch.ones(256, device=dev), torch.zeros(256, device=dev)
 g1k, b1k = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
@@ -30,6 +35,13 @@ s2r = torch.zeros(16, 512, device=dev)
 def fwd(variant):
     x = x0
     for l in range(NL):
+        if variant == 3:
+            ops.conv1x1_kstream(x, W1k[l], 256, stats=s1r, stats_replicas=16, out=y1)
+            ops.conv3x3_img(y1, W2i[l], 256, stats=s2r, stats_replicas=16, out=y2, in_bn=dict(stats=s1r, gamma=g256, beta=b256, count=n, replicas=16))
+            ops.conv1x1_astat(y2, W3a[l], 1024, stats=s3r, stats_replicas=4, out=y3, in_bn=dict(stats=s2r, gamma=g256, beta=b256, count=n, replicas=16))
+            ops.bn_act(y3, g1k, b1k, stats=s3r, stats_replicas=4, count=n, relu=True, res=x, out=y3)
+            x = y3
+            continue
         ops.conv_nhwc(x, W1[l], 1, 1, 1, 0, stats=s1, out=y1)
         if variant == 0:
             ops.bn_act(y1, g256, b256, stats=s1, count=n, relu=True, out=y1)
