@@ -60,16 +60,17 @@ __global__ __launch_bounds__(256) void ncp_to_pf_kernel(const float* __restrict_
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ att1, const float* __restrict__ att2,
-                                                       const float* __restrict__ wf, const float* __restrict__ bf,
-                                                       const T* __restrict__ feat, float* __restrict__ alpha_out, long alpha_stride,
-                                                       T* __restrict__ z, int P, int A, int F) {
+__global__ __launch_bounds__(1024) void attn_fwd_kernel(const T* __restrict__ att1, const float* __restrict__ att2,
+                                                        const float* __restrict__ wf, const float* __restrict__ bf,
+                                                        const T* __restrict__ feat, float* __restrict__ alpha_out, long alpha_stride,
+                                                        T* __restrict__ z, int P, int A, int F) {
   __shared__ float e[kMaxP];
+  extern __shared__ float zred[];                      // [G][F] partial context vectors (G > 1 only)
   constexpr int N = V16<T>::N;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const T* a1 = att1 + (long)b * P * A;
   const float* a2 = att2 + (long)b * A;
-  for (int p = wid; p < P; p += 4) {
+  for (int p = wid; p < P; p += nw) {
     float s = 0.f;
     for (int c = lane * N; c < A; c += 64 * N) {
       float v[N];
@@ -94,36 +95,72 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ att
   }
   __syncthreads();
   const T* fb = feat + (long)b * P * F;
-  for (int c = threadIdx.x * N; c < F; c += blockDim.x * N) {
+  const int nchunk = F / N;                            // 16-byte channel chunks
+  const int G = (int)blockDim.x >= 2 * nchunk ? (int)blockDim.x / nchunk : 1;   // pixel groups per chunk
+  if (G == 1) {
+    for (int c = threadIdx.x * N; c < F; c += blockDim.x * N) {
+      float acc[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = 0.f;
+      for (int p = 0; p < P; ++p) {
+        float v[N];
+        V16<T>::load(fb + (long)p * F + c, v);
+        const float al = e[p];
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] += al * v[k];
+      }
+      V16<T>::store(z + (long)b * F + c, acc);
+    }
+    return;
+  }
+  // 16 waves, fewer chunks than threads: (chunk, pixel group) per thread; the groups' partial sums meet in LDS and are added
+  // in pixel order (group 0 first), so the sum is associated per group, not per pixel
+  const int ci = threadIdx.x % nchunk, g = threadIdx.x / nchunk, c = ci * N;
+  if (g < G) {
+    const int per = (P + G - 1) / G, p0 = g * per, p1 = p0 + per < P ? p0 + per : P;
     float acc[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k] = 0.f;
-    for (int p = 0; p < P; ++p) {
+    for (int p = p0; p < p1; ++p) {
       float v[N];
       V16<T>::load(fb + (long)p * F + c, v);
       const float al = e[p];
 #pragma unroll
       for (int k = 0; k < N; ++k) acc[k] += al * v[k];
     }
+#pragma unroll
+    for (int k = 0; k < N; ++k) zred[(long)g * F + c + k] = acc[k];
+  }
+  __syncthreads();
+  if (g == 0) {
+    float acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = zred[c + k];
+    for (int q = 1; q < G; ++q)
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] += zred[(long)q * F + c + k];
     V16<T>::store(z + (long)b * F + c, acc);
   }
 }
 
-// backward of one attention step for sample b (see attn.cpp for the algebra)
+// backward of one attention step for sample b (see attn.cpp for the algebra).  One workgroup per sample, but 16 waves of it
+// (1024 threads): at B = 64 only 64 workgroups exist, so the parallelism has to come from inside -- the 49 dz . feat_p dot
+// products take 4 rounds of the 16 waves instead of 13 of 4, and the channel pass is split over (channel, pixel group).
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ dalpha_extra, long extra_stride,
-                                                       const float* __restrict__ alpha, long alpha_stride,
-                                                       const T* __restrict__ att1, const float* __restrict__ att2,
-                                                       const float* __restrict__ wf, const T* __restrict__ feat,
-                                                       float* __restrict__ datt2, float* __restrict__ datt1_acc,
-                                                       float* __restrict__ dwf, float* __restrict__ dbf, int P, int A, int F) {
+__global__ __launch_bounds__(1024) void attn_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ dalpha_extra, long extra_stride,
+                                                        const float* __restrict__ alpha, long alpha_stride,
+                                                        const T* __restrict__ att1, const float* __restrict__ att2,
+                                                        const float* __restrict__ wf, const T* __restrict__ feat,
+                                                        float* __restrict__ datt2, float* __restrict__ datt1_acc,
+                                                        float* __restrict__ dwf, float* __restrict__ dbf, int P, int A, int F) {
   __shared__ float da[kMaxP], de[kMaxP];
+  extern __shared__ float red[];                       // [2][G][A] partial sums of the channel pass (G > 1 only)
   constexpr int N = V16<T>::N;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const T* fb = feat + (long)b * P * F;
   const float* dzb = dz + (long)b * F;
   // d alpha_p = dz . feat_p + regulariser term
-  for (int p = wid; p < P; p += 4) {
+  for (int p = wid; p < P; p += nw) {
     float s = 0.f;
     for (int c = lane * N; c < F; c += 64 * N) {
       float v[N];
@@ -148,16 +185,41 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const T* a1 = att1 + (long)b * P * A;
   const float* a2 = att2 + (long)b * A;
   float* d1 = datt1_acc + (long)b * P * A;
-  for (int c = threadIdx.x; c < A; c += blockDim.x) {
+  const int G = (int)blockDim.x >= 2 * A ? (int)blockDim.x / A : 1;   // pixel groups per channel
+  if (G == 1) {
+    for (int c = threadIdx.x; c < A; c += blockDim.x) {
+      const float w = wf[c], t2 = a2[c];
+      float s2 = 0.f, sw = 0.f;
+      for (int p = 0; p < P; ++p) {
+        const float u = to_f32<T>(a1[(long)p * A + c]) + t2;
+        const float du = de[p] * w * (u > 0.f ? 1.f : 0.2f);
+        s2 += du;
+        sw += de[p] * lrelu(u);
+        d1[(long)p * A + c] += du;          // only this block touches (b, :, :): plain read-modify-write
+      }
+      datt2[(long)b * A + c] = s2;
+      atomicAdd(dwf + c, sw);
+    }
+    return;
+  }
+  const int c = threadIdx.x % A, g = threadIdx.x / A;
+  if (g < G) {
+    const int per = (P + G - 1) / G, p0 = g * per, p1 = p0 + per < P ? p0 + per : P;
     const float w = wf[c], t2 = a2[c];
     float s2 = 0.f, sw = 0.f;
-    for (int p = 0; p < P; ++p) {
+    for (int p = p0; p < p1; ++p) {
       const float u = to_f32<T>(a1[(long)p * A + c]) + t2;
       const float du = de[p] * w * (u > 0.f ? 1.f : 0.2f);
       s2 += du;
       sw += de[p] * lrelu(u);
-      d1[(long)p * A + c] += du;          // only this block touches (b, :, :): plain read-modify-write
+      d1[(long)p * A + c] += du;
     }
+    red[g * A + c] = s2; red[(G + g) * A + c] = sw;
+  }
+  __syncthreads();
+  if (g == 0) {
+    float s2 = 0.f, sw = 0.f;
+    for (int q = 0; q < G; ++q) { s2 += red[q * A + c]; sw += red[(G + q) * A + c]; }
     datt2[(long)b * A + c] = s2;
     atomicAdd(dwf + c, sw);
   }
@@ -229,8 +291,12 @@ int attn_fwd_launch(const void* att1, const float* att2, const float* wf, const 
   if (n <= 0) return 0;
   const int nn = dtype == ST_BF16 ? 8 : 4;
   ST_CHECK(A % nn == 0 && F % nn == 0 && P <= kMaxP, "attention: A=%d and F=%d must be multiples of %d, P=%d <= %d", A, F, nn, P, kMaxP);
-  if (dtype == ST_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(n), dim3(256), 0, st, (const bf16_t*)att1, att2, wf, bf, (const bf16_t*)feat, alpha_out, alpha_stride, (bf16_t*)z, P, A, F);
-  else hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(n), dim3(256), 0, st, (const float*)att1, att2, wf, bf, (const float*)feat, alpha_out, alpha_stride, (float*)z, P, A, F);
+  const int threads = n < 512 ? 1024 : 256;           // few samples: the parallelism comes from inside the workgroup (attn_bwd_kernel)
+  const int nchunk = F / nn;
+  const int G = threads >= 2 * nchunk ? threads / nchunk : 1;
+  const size_t lds = G > 1 ? (size_t)G * F * sizeof(float) : 0;
+  if (dtype == ST_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(n), dim3(threads), lds, st, (const bf16_t*)att1, att2, wf, bf, (const bf16_t*)feat, alpha_out, alpha_stride, (bf16_t*)z, P, A, F);
+  else hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(n), dim3(threads), lds, st, (const float*)att1, att2, wf, bf, (const float*)feat, alpha_out, alpha_stride, (float*)z, P, A, F);
   ST_LAUNCH_CHECK();
   return 0;
 }
@@ -239,8 +305,12 @@ int attn_bwd_launch(const float* dz, const float* dalpha_extra, long extra_strid
                     const void* att1, const float* att2, const float* wf, const void* feat, float* datt2, float* datt1_acc,
                     float* dwf, float* dbf, int n, int P, int A, int F, int dtype, hipStream_t st) {
   if (n <= 0) return 0;
-  if (dtype == ST_BF16) hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(n), dim3(256), 0, st, dz, dalpha_extra, extra_stride, alpha, alpha_stride, (const bf16_t*)att1, att2, wf, (const bf16_t*)feat, datt2, datt1_acc, dwf, dbf, P, A, F);
-  else hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(n), dim3(256), 0, st, dz, dalpha_extra, extra_stride, alpha, alpha_stride, (const float*)att1, att2, wf, (const float*)feat, datt2, datt1_acc, dwf, dbf, P, A, F);
+  // 1024 threads per sample while the launch cannot fill the chip with 256-thread workgroups (BASELINE config 3: 64 samples)
+  const int threads = n < 512 ? 1024 : 256;
+  const int G = threads >= 2 * A ? threads / A : 1;
+  const size_t lds = G > 1 ? (size_t)2 * G * A * sizeof(float) : 0;
+  if (dtype == ST_BF16) hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(n), dim3(threads), lds, st, dz, dalpha_extra, extra_stride, alpha, alpha_stride, (const bf16_t*)att1, att2, wf, (const bf16_t*)feat, datt2, datt1_acc, dwf, dbf, P, A, F);
+  else hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(n), dim3(threads), lds, st, dz, dalpha_extra, extra_stride, alpha, alpha_stride, (const float*)att1, att2, wf, (const float*)feat, datt2, datt1_acc, dwf, dbf, P, A, F);
   ST_LAUNCH_CHECK();
   return 0;
 }

@@ -94,3 +94,59 @@ def test_attention_config3_shape_vs_oracle(dtype):
             assert p_.grad.abs().max().item() < (1e-5 if dtype == torch.float32 else 1e-2)
             continue
         assert _rel(p_.grad, po[k].grad) < (1e-3 if dtype == torch.float32 else 6e-2), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_full_config3_size(dtype):
+    """BASELINE configs[2] at its FULL size (Attention/main_attn.py:123-134, rnn_attn.py:60-118): B = 64, L = 5, V = 10000,
+    F = 2048, P = 49, A = E = H = 512, alpha_c = 1.  The whole batch is too slow for the CPU oracle inside the GPU suite, so:
+    the 8 longest captions' logits rows and alphas against the oracle run on those 8 samples alone (rows are independent
+    in the forward), plus the properties of the full batch: alphas rows sum to one on live steps and are zero on padded
+    ones, loss = CE + alpha_c * mean((1 - sum_t alpha)^2) recomputed from the returned logits / alphas, finite gradients
+    on every parameter, and a second SGD step on the same batch lowers the loss."""
+    from showtell_amd import optim
+    E, Fd, A, H, V, L, B = 512, 2048, 512, 512, 10000, 5, 64
+    params = R.init_decoder_params(E, H, V, L, "gru", seed=21, attn=dict(F=Fd, A=A))
+    if dtype == torch.bfloat16:
+        params = {k: v.bfloat16().float() for k, v in params.items()}
+    m = _make("gru", params, dtype).train()
+    cap, lens = R.synthetic_captions(B, V, seed=21)
+    feat = torch.randn(B, Fd, 49, generator=torch.Generator().manual_seed(21)).abs()
+    if dtype == torch.bfloat16:
+        feat = feat.bfloat16().float()
+    logits, alphas = m(feat.cuda(), cap.cuda(), lens)
+    ntok = sum(lens)
+    assert logits.shape == (ntok, V) and alphas.shape == (B, lens[0], 49)
+    s = alphas.sum(2).cpu()
+    for b, l in enumerate(lens):
+        assert torch.allclose(s[b, :l], torch.ones(l), atol=2e-3) and float(s[b, l:].abs().sum()) == 0.0
+    # the 8 longest captions against the oracle
+    S = 8
+    with torch.no_grad():
+        _, lo8, al8 = R.attn_train_loss({k: v.clone() for k, v in params.items()}, feat[:S], cap[:S, :lens[0]], lens[:S], 1.0, "gru")
+    bs_full = [sum(1 for l in lens if l > t) for t in range(lens[0])]
+    bs8 = [sum(1 for l in lens[:S] if l > t) for t in range(lens[0])]
+    rows_full, rows8, of, o8 = [], [], 0, 0
+    for t in range(lens[0]):
+        for b in range(bs8[t]):
+            rows_full.append(of + b); rows8.append(o8 + b)
+        of += bs_full[t]; o8 += bs8[t]
+    tol = 5e-4 if dtype == torch.float32 else 6e-2
+    got = logits[torch.tensor(rows_full, device="cuda")].float().cpu()
+    assert _rel(got, lo8[torch.tensor(rows8)]) < tol
+    assert _rel(alphas[:S].float().cpu(), al8) < tol
+    # loss of the fused route = CE(logits) + alpha_c * mean((1 - sum_t alpha)^2) of what forward() returned (main_attn.py:128-131)
+    target = nn.utils.rnn.pack_padded_sequence(cap.cuda(), lens, batch_first=True)[0]
+    want = nn.functional.cross_entropy(logits.float(), target) + ((1.0 - alphas.float().sum(1)) ** 2).mean()
+    opt = optim.SGD(list(m.parameters()), lr=0.05, momentum=0.9, shadow_dtype=None if dtype == torch.float32 else dtype)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = m.loss(feat.cuda(), cap.cuda(), lens, 1.0)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert abs(losses[0] - float(want)) < (2e-4 if dtype == torch.float32 else 3e-2) * max(1.0, float(want))
+    assert abs(losses[0] - np.log(V)) < 1.0 and losses[-1] < losses[0], losses
+    for k, p_ in m.named_parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
