@@ -254,16 +254,24 @@ def main():
     trainer.flush()
     torch.cuda.synchronize()
     if rank == 0:
-        ms, fl, n = (C.c_double * 16)(), (C.c_double * 16)(), (C.c_long * 16)()
+        ms, fl, n = (C.c_double * 32)(), (C.c_double * 32)(), (C.c_long * 32)()
         lib().st_prof_collect(ms, fl, n)
         lib().st_prof_enable(0)
-        names = {0: "128x128-tile igemm family: igemm_kernel<bf16,128,128,2,4,{8,4},{1,2}> + igemm_s3b_kernel", 1: "igemm_kernel<bf16,128,64,4,1,8>",
-                 2: "igemm_kernel<bf16,64,128,1,4,8>", 3: "igemm_kernel<bf16,256,128,4,2,8>",
-                 8: "conv3x3_img_kernel (image-resident 3x3, csrc/conv_img.hip)", 9: "conv1x1_wreg_kernel (pointwise, filter slice in registers, csrc/conv_img.hip)",
-                 10: "conv1x1_kstream_kernel (pointwise, long K, csrc/conv_img.hip)", 11: "conv1x1_astat_kernel (pointwise, activation-stationary, csrc/conv_img.hip)"}
-        prefixes = {0: ("igemm_kernel<bf16,128,128,2,4,", "igemm_s3b_kernel"), 8: ("conv3x3_img_kernel",), 9: ("conv1x1_wreg_kernel",),
-                    10: ("conv1x1_kstream_kernel",), 11: ("conv1x1_astat_kernel",)}
-        v = max(range(16), key=lambda i: ms[i])
+        names = {0: "igemm 128x128-tile family: igemm_kernel<bf16,128,128,2,4,{8,4},{1,2}> + igemm_s3b_kernel", 1: "igemm_kernel<bf16,128,64,4,1,8>",
+                 2: "igemm_kernel<bf16,64,128,1,4,8>", 3: "igemm_kernel<bf16,256,128,4,2,8>"}
+        prefixes = {0: ("igemm_kernel<bf16,128,128,2,4,", "igemm_s3b_kernel")}
+        for i_, c_ in enumerate((64, 128, 256, 512)):          # csrc/conv_img.hip: one slot per kernel symbol (csrc/prof.h)
+            names[8 + i_] = "conv3x3_img_kernel<%d,...> (image-resident 3x3, csrc/conv_img.hip)" % c_
+            prefixes[8 + i_] = ("conv3x3_img_kernel<%d," % c_,)
+            names[12 + i_] = "conv1x1_wreg_kernel<%d,...> (pointwise, filter slice in registers, csrc/conv_img.hip)" % c_
+            prefixes[12 + i_] = ("conv1x1_wreg_kernel<%d," % c_,)
+        for i_, c_ in enumerate((1024, 2048)):
+            names[16 + i_] = "conv1x1_kstream_kernel<%d,...> (pointwise, long K, csrc/conv_img.hip)" % c_
+            prefixes[16 + i_] = ("conv1x1_kstream_kernel<%d," % c_,)
+        for i_, c_ in enumerate((256, 512)):
+            names[18 + i_] = "conv1x1_astat_kernel<%d,...> (pointwise, activation-stationary, csrc/conv_img.hip)" % c_
+            prefixes[18 + i_] = ("conv1x1_astat_kernel<%d," % c_,)
+        v = max(range(32), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12 if ms[v] > 0 else 0.0
         tot_ms, tot_fl = sum(ms), sum(fl)
         # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process; the figure comes from the
@@ -285,8 +293,8 @@ def main():
                 "avg_launch_us": round(ms[v] * 1e3 / max(1, n[v]), 2),
                 "all_conv_TFLOPs": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                 "all_conv_ms_per_step": round(tot_ms / max(1, a.profile_steps), 3),
-                "by_kernel": {names.get(i, f"variant{i}").split(" ")[0].split(":")[0]: {"ms_per_step": round(ms[i] / max(1, a.profile_steps), 3), "launches": int(n[i]),
-                                                                       "TFLOPs": round(fl[i] / (ms[i] * 1e-3) / 1e12, 1)} for i in range(16) if n[i] > 0}}
+                "by_kernel": {names.get(i, f"variant{i}").split(" (")[0].split(":")[0]: {"ms_per_step": round(ms[i] / max(1, a.profile_steps), 3), "launches": int(n[i]),
+                                                                       "TFLOPs": round(fl[i] / (ms[i] * 1e-3) / 1e12, 1)} for i in range(32) if n[i] > 0}}
     _progress("phases")
     # ---- per-phase split of one plain (unpipelined) step, SURVEY 8(d) config 2: HIP events on the launch stream ----------
     phases = None

@@ -127,6 +127,18 @@ int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream);
  * (fragment-major filters, ntw = 4).  Same descriptor; in_stats and residual must be NULL. */
 int st_conv1x1_kstream_supported(int C, int N);
 int st_conv1x1_kstream(const st_conv1x1_wreg_desc* d, void* stream);
+/* conv1 of a Bottleneck fused with the PREVIOUS block's end (torchvision Bottleneck.forward: out = relu(bn3(conv3(..)) + identity),
+ * then the next block's conv1(out); reference cnn.py:46), train mode, C = 1024 -> N = 256 (layer3):
+ *   x_out = relu(batchnorm(raw; f_stats, f_gamma, f_beta) + identity)   -- written once, it is the next identity
+ *   y     = x_out (*) w_frag (1x1, ntw = 4 fragment-major weights),  stats += [sum | sumsq] of y
+ * raw / identity / x_out: [rows][1024] bf16, y: [rows][256] bf16.  Replaces one st_bn_act pass + st_conv1x1_kstream. */
+typedef struct {
+  const void* raw; const void* identity; void* x_out; const void* w_frag; void* y;
+  float* stats; int stats_replicas;
+  const float* f_stats; const float* f_gamma; const float* f_beta; float f_count; float f_eps; int f_stats_replicas;
+  long rows; int C, N;
+} st_conv1x1_kfuse_desc;
+int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream);
 /* The activation-stationary sibling for (C, N) = (256, 1024) / (512, 2048) (conv3 of the layer3 / layer4 Bottlenecks): a
  * workgroup keeps its 112 x C rows in LDS (producer's BatchNorm + ReLU applied once per element) and walks all N output
  * channels barrier-free.  Same descriptor (ntw = 4 weights), stride 1, residual NULL. */
@@ -140,8 +152,9 @@ int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream);
 int st_pack_conv_weight_frag(const float* w, void* out, int Cout, int Cin, int KH, int KW, int ntw, void* stream);
 
 /* Launch profiler for bench.py's roofline: HIP events around every convolution launch on its stream.
- * st_prof_collect fills 16-entry arrays indexed by kernel variant (0: bf16 128x128 tile family,
- * 1: bf16 128x64, 2: bf16 64x128, 3: 256x128, 4..7 the same for f32, 8: st_conv3x3_img, 9: st_conv1x1_wreg, 10: st_conv1x1_kstream, 11: st_conv1x1_astat; csrc/prof.h); synchronise the device first. */
+ * st_prof_collect fills 32-entry arrays indexed by kernel variant (0: bf16 128x128 tile family,
+ * 1: bf16 128x64, 2: bf16 64x128, 3: 256x128, 4..7 the same for f32, 8..19: the csrc/conv_img.hip kernels, one slot per kernel symbol
+ * (csrc/prof.h)); synchronise the device first. */
 int st_tune(int reserved, int kc, int w8);   /* main-loop variant knobs for tools/bench_conv.py (row chunk count 4|8, block shape); -1 = keep */
 int st_prof_enable(int on);
 /* debug aid: per-block phase timestamps of st_conv launches (tools/conv_stamps.py); NULL = off (default) */

@@ -35,6 +35,12 @@ class Conv1x1WregDesc(C.Structure):
                 ("in_stats_replicas", c_i), ("B", c_i), ("Hin", c_i), ("Win", c_i), ("C", c_i), ("N", c_i), ("stride", c_i)]
 
 
+class Conv1x1KfuseDesc(C.Structure):
+    _fields_ = [("raw", c_p), ("identity", c_p), ("x_out", c_p), ("w_frag", c_p), ("y", c_p), ("stats", c_p), ("stats_replicas", c_i),
+                ("f_stats", c_p), ("f_gamma", c_p), ("f_beta", c_p), ("f_count", c_f), ("f_eps", c_f), ("f_stats_replicas", c_i),
+                ("rows", c_l), ("C", c_i), ("N", c_i)]
+
+
 class BnActDesc(C.Structure):
     _fields_ = [("x", c_p), ("y", c_p), ("res", c_p), ("stats", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("res_stats", c_p), ("res_gamma", c_p),
@@ -88,6 +94,7 @@ _SIGS = {
     "st_conv3x3_img": ([C.POINTER(Conv3x3ImgDesc), c_p], c_i),
     "st_conv1x1_wreg_supported": ([c_i, c_i], c_i),
     "st_conv1x1_wreg": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
+    "st_conv1x1_kfuse": ([C.POINTER(Conv1x1KfuseDesc), c_p], c_i),
     "st_conv1x1_astat_supported": ([c_i, c_i], c_i),
     "st_conv1x1_astat": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_conv1x1_kstream_supported": ([c_i, c_i], c_i),

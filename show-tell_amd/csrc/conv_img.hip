@@ -797,6 +797,172 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef AS_STAMP
 }
 
+// =====================================================================================================================
+// conv1 of a Bottleneck FUSED WITH THE PREVIOUS BLOCK'S END: x = relu(bn3(raw3) + identity) is what conv1 (1024 -> 256)
+// reads, and in torchvision's graph it is also the next identity.  Here the K-streaming kernel's loader forms x itself --
+// it loads the raw conv3 output and the identity, applies bn3 (batch statistics of the raw tensor, replicated, summed in the
+// prologue) + add + ReLU on the way to LDS and writes x back once (every activation row belongs to exactly ONE workgroup at
+// N = 256, so nothing is recomputed).  The separate normalise pass (read raw + identity, write x: 154 MB per layer3 block at
+// B = 128, ~20 us + a launch) disappears, and so does conv1's own read of x.  The transform of slab s+1 is spread over the four
+// K-steps of slab s (two 16-byte chunks per K-step and thread), under that slab's MFMAs.
+struct KfArgs {
+  const bf16_t* raw; const bf16_t* res; bf16_t* xout; const bf16_t* w; bf16_t* y;
+  float* stats; int srep;
+  const float* f_stats; const float* f_gamma; const float* f_beta; float f_count, f_eps; int f_srep;
+  int M;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_kfuse_kernel(KfArgs a) {
+  constexpr int TM = 7, NTW = 4, BM = 16 * TM, N = 256;
+  constexpr int SLAB = 128, PIX = 2 * SLAB + 32, KSS = SLAB / 32;
+  constexpr int NSLAB = K / SLAB, KS = K / 32;
+  constexpr int SLAB_BYTES = BM * PIX;
+  constexpr int NL = BM * (SLAB / 8) / 256;                            // 7
+  constexpr int WR = 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem + 2 * SLAB_BYTES);       // [scale(K) | shift(K)] of the previous block's bn3
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bm;
+  {
+    const int nblk = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    bm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int T0 = wid * NTW;
+  const u32x4* wl = reinterpret_cast<const u32x4*>(a.w) + lane;
+
+  const int cch = tid & 15, lrow = tid >> 4;
+  long roff[NL]; bool rok[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int m = bm * BM + lrow + 16 * i;
+    rok[i] = m < a.M;
+    m = rok[i] ? m : a.M - 1;
+    roff[i] = (long)m * K + cch * 8;
+  }
+  u32x4 rr[NL], rs[NL];
+  auto gload1 = [&](int i, int slab) {
+    const int sl = slab < NSLAB ? slab : NSLAB - 1;
+    rr[i] = *reinterpret_cast<const u32x4*>(a.raw + roff[i] + sl * SLAB);
+    rs[i] = *reinterpret_cast<const u32x4*>(a.res + roff[i] + sl * SLAB);
+  };
+  // x = relu(raw * sc + sh + res) for chunk i of `slab`, to the LDS ring half `buf` and (once) back to memory
+  auto xform1 = [&](int i, int slab, int buf) {
+    const float* cs = coef + slab * SLAB + cch * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(cs + e), h4 = *reinterpret_cast<const f32x4*>(cs + K + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { sc[e + q] = s4[q]; sh[e + q] = h4[q]; }
+    }
+    u32x4 v;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float lo = fmaxf(__uint_as_float(rr[i][d] << 16) * sc[2 * d] + sh[2 * d] + __uint_as_float(rs[i][d] << 16), 0.f);
+      const float hi = fmaxf(__uint_as_float(rr[i][d] & 0xffff0000u) * sc[2 * d + 1] + sh[2 * d + 1] + __uint_as_float(rs[i][d] & 0xffff0000u), 0.f);
+      v[d] = pack_bf16x2(lo, hi);
+    }
+    *reinterpret_cast<u32x4*>(smem + buf * SLAB_BYTES + (lrow + 16 * i) * PIX + cch * 16) = v;
+    if (rok[i]) *reinterpret_cast<u32x4*>(a.xout + roff[i] + slab * SLAB) = v;
+  };
+
+#pragma unroll
+  for (int i = 0; i < NL; ++i) gload1(i, 0);
+  u32x4 wq[WR][NTW];
+#pragma unroll
+  for (int s = 0; s < WR; ++s)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wq[s][j] = wl[((size_t)(T0 + j) * KS + s) * 64];
+  {
+    const float inv = 1.0f / a.f_count;
+    for (int c = tid; c < K; c += 256) {
+      float sm = 0.f, sq = 0.f;
+      for (int r = 0; r < a.f_srep; ++r) { sm += a.f_stats[(size_t)r * 2 * K + c]; sq += a.f_stats[(size_t)r * 2 * K + K + c]; }
+      const float mean = sm * inv;
+      const float var = fmaxf(sq * inv - mean * mean, 0.f);
+      const float scv = a.f_gamma[c] * rsqrtf(var + a.f_eps);
+      coef[c] = scv; coef[K + c] = a.f_beta[c] - mean * scv;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { xform1(i, 0, 0); gload1(i, 1); }
+  __syncthreads();
+
+  f32x4 acc[TM][NTW];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* abase = smem + r16 * PIX + q4 * 16;
+
+  u32x4 fa0[TM], fa1[TM];
+#pragma unroll
+  for (int s = 0; s < NSLAB; ++s) {
+    const char* ab = abase + (s & 1) * SLAB_BYTES;
+    auto read_a = [&](u32x4 (&f)[TM], int kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f[i] = *reinterpret_cast<const u32x4*>(ab + i * 16 * PIX + kk * 64);
+    };
+    read_a(fa0, 0);
+#pragma unroll
+    for (int kk = 0; kk < KSS; ++kk) {
+      const int ks = s * KSS + kk;
+      u32x4 (&fa)[TM] = (kk & 1) ? fa1 : fa0;
+      u32x4 (&fn)[TM] = (kk & 1) ? fa0 : fa1;
+      if (kk + 1 < KSS) read_a(fn, kk + 1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = mfma_bf16(wq[ks % WR][j], fa[i], acc[i][j]);
+      if (ks + WR < KS) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) wq[ks % WR][j] = wl[((size_t)(T0 + j) * KS + ks + WR) * 64];
+      }
+      if (s + 1 < NSLAB) {                              // this K-step's share of the next slab: chunks 2kk, 2kk+1 (7 over 4 K-steps)
+#pragma unroll
+        for (int i = 2 * kk; i < 2 * kk + 2 && i < NL; ++i) { xform1(i, s + 1, (s + 1) & 1); gload1(i, s + 2); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  constexpr int NC = 4 * NTW;
+  const int cb = T0 * 16 + NC * q4;
+  float es[NC], ess[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = bm * BM + i * 16 + r16;
+    if (m < a.M) {
+      float v[NC];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
+      bf16_t* dst = a.y + (size_t)m * N + cb;
+#pragma unroll
+      for (int h = 0; h < NTW / 2; ++h)
+        *reinterpret_cast<u32x4*>(dst + 8 * h) = u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                                       pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+    }
+  }
+  if (a.stats) {
+    float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * N : 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
+    block_stats_flush<NC, 64 * NTW>(es, ess, r16 == 0, wid * 16 * NTW + NC * q4, smem, sdst, 0, N, tid);
+  }
+}
+
 // ---- fragment-major filter bank ---------------------------------------------------------------------------------
 // out[((T * KS + ks) * 64 + lane) * 8 + j], T = 16-channel tile, ks = 32-deep K step (k = tap * Cin + c), lane = (q4, r16):
 // MFMA row r16 of tile T is output channel ch(T, r16) = (T / NTW) * 16 NTW + 4 NTW (r16 / 4) + 4 (T % NTW) + r16 % 4
@@ -838,7 +1004,7 @@ int launch_img(const ImgArgs& a, int lds, hipStream_t st, double flops) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel<C, TM, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 160 * 1024;
   }
-  StProfScope prof(8, flops, st);
+  StProfScope prof(C == 64 ? 8 : C == 128 ? 9 : C == 256 ? 10 : 11, flops, st);
   hipLaunchKernelGGL((conv3x3_img_kernel<C, TM, NTW>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
@@ -929,7 +1095,7 @@ int launch_pw___(PwArgs& a, hipStream_t st, double flops, bool xf) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
-  StProfScope prof(9, flops, st);
+  StProfScope prof(K == 64 ? 12 : K == 128 ? 13 : K == 256 ? 14 : 15, flops, st);
   hipLaunchKernelGGL((conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE>), dim3(mbs * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
@@ -1004,7 +1170,7 @@ int launch_ks_(KsArgs& a, hipStream_t st, double flops) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_kstream_kernel<K, STRIDED, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set[dev] = 1;
   }
-  StProfScope prof(10, flops, st);
+  StProfScope prof(K == 1024 ? 16 : 17, flops, st);
   hipLaunchKernelGGL((conv1x1_kstream_kernel<K, STRIDED, AFFINE>), dim3(((a.M + 111) / 112) * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
@@ -1029,7 +1195,7 @@ int launch_as_(AsArgs& a, hipStream_t st, double flops) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_astat_kernel<K, NCH, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
-  StProfScope prof(11, flops, st);
+  StProfScope prof(K == 256 ? 18 : 19, flops, st);
   hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE>), dim3((a.M + 111) / 112), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
@@ -1060,6 +1226,35 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   const double flops = 2.0 * (double)M * d->N * d->C;
   if (d->C == 256) return a.scale ? launch_as_<256, 4, true>(a, st, flops) : launch_as_<256, 4, false>(a, st, flops);
   return a.scale ? launch_as_<512, 8, true>(a, st, flops) : launch_as_<512, 8, false>(a, st, flops);
+}
+
+// conv1 (C -> 256, C = 1024) fused with the previous block's end; see st_conv1x1_kfuse_desc in the header
+extern "C" int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream) {
+  ST_CHECK(d && d->raw && d->identity && d->x_out && d->w_frag && d->y && d->f_stats && d->f_gamma && d->f_beta, "st_conv1x1_kfuse: null pointer");
+  ST_CHECK(d->C == 1024 && d->N == 256, "st_conv1x1_kfuse: C=%d N=%d (1024 -> 256 only)", d->C, d->N);
+  ST_CHECK(d->rows > 0 && d->f_count > 0.f && d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->f_stats_replicas >= 0 && d->f_stats_replicas <= 1024,
+           "st_conv1x1_kfuse: bad rows / count / replicas");
+  KfArgs a;
+  a.raw = reinterpret_cast<const bf16_t*>(d->raw); a.res = reinterpret_cast<const bf16_t*>(d->identity); a.xout = reinterpret_cast<bf16_t*>(d->x_out);
+  a.w = reinterpret_cast<const bf16_t*>(d->w_frag); a.y = reinterpret_cast<bf16_t*>(d->y);
+  a.stats = d->stats; a.srep = d->stats_replicas;
+  a.f_stats = d->f_stats; a.f_gamma = d->f_gamma; a.f_beta = d->f_beta; a.f_count = d->f_count; a.f_eps = d->f_eps;
+  a.f_srep = d->f_stats_replicas > 1 ? d->f_stats_replicas : 1;
+  a.M = (int)d->rows;
+  constexpr int lds = 2 * 112 * (2 * 128 + 32) + 2 * 1024 * 4;
+  static int attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_kfuse_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set[dev] = 1;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  StProfScope prof(16, 2.0 * (double)d->rows * 256.0 * 1024.0, st);
+  hipLaunchKernelGGL((conv1x1_kfuse_kernel<1024>), dim3((a.M + 111) / 112), dim3(256), lds, st, a);
+  prof.end(st);
+  ST_LAUNCH_CHECK();
+  return 0;
 }
 
 // 4: supported (the `ntw` of the fragment-major weights); 0: use st_conv

@@ -122,7 +122,17 @@ template <int N> __device__ __forceinline__ void bn_coeff_vec(const float* stats
   ldf<N>(stats ? stats + C + c : rvar + c, b);
   if (stats) {   // replicated statistics ([reps][2C], st_conv_desc.stats_replicas): summed here -- a thread reads 2 x 32 bytes per
                  // replica for its own channels, cheaper than a reduction launch in front of every normalise pass
-    for (int r = 1; r < reps; ++r) {
+    int r = 1;
+    for (; r + 3 <= reps; r += 3) {      // three replicas per round trip (the loads of a round are independent)
+      float a2[3][N], b2[3][N];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { ldf<N>(stats + (size_t)(r + q) * 2 * C + c, a2[q]); ldf<N>(stats + (size_t)(r + q) * 2 * C + C + c, b2[q]); }
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k = 0; k < N; ++k) { a[k] += a2[q][k]; b[k] += b2[q][k]; }
+    }
+    for (; r < reps; ++r) {
       float a2[N], b2[N];
       ldf<N>(stats + (size_t)r * 2 * C + c, a2);
       ldf<N>(stats + (size_t)r * 2 * C + C + c, b2);

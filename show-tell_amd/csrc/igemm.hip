@@ -997,7 +997,7 @@ extern "C" int st_prof_enable(int on) {
 }
 
 // Sums per kernel variant (0: bf16 128x128, 1: bf16 128x64, 2: bf16 64x128, 4..6: the f32 forms).
-// The caller must have synchronised the stream(s).  Arrays must hold 16 entries (prof.h lists the variants).
+// The caller must have synchronised the stream(s).  Arrays must hold 32 entries (prof.h lists the variants).
 extern "C" int st_prof_collect(double* ms, double* flops, long* launches) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int v = 0; v < kVariants; ++v) { ms[v] = 0; flops[v] = 0; launches[v] = 0; }

@@ -21,7 +21,11 @@
 #include <stdlib.h>
 
 struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; int korder; size_t woff_frag; int ntw; };   // woff_frag: fragment-major copy for st_conv3x3_img (ntw > 0)
-struct BlockL { int c1, c2, c3, ds; int stride; };  // indices into convs (c3 = -1 for basic blocks, ds = -1 if none)
+struct BlockL { int c1, c2, c3, ds; int stride; };
+// The activation-stationary pointwise kernel (one workgroup per 112 rows) takes the 256 -> 1024 conv3 of layer3; layer4's 512 -> 2048
+// has only 49 rows per image (56 workgroups at B = 128: measured 63 us against 32 on st_conv1x1_wreg) and stays there.  Static per
+// layer: the fragment-major copy is packed for ONE kernel's channel permutation (ntw).
+static inline bool use_astat(const ConvL& c) { return c.k == 1 && c.stride == 1 && c.cin == 256 && c.cout == 1024; }  // indices into convs (c3 = -1 for basic blocks, ds = -1 if none)
 
 struct BnTable { int n; int end[160]; float count[160]; int soff[160]; int rep[160]; };   // soff: float offset of the layer's [rep][2C] statistics
 struct PendingUpdate { BnTable tab; const float* stats; };
@@ -122,7 +126,7 @@ extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
     // pointwise layers with <= 512 input channels: fragment-major copy for the register-resident-filter kernel (st_conv1x1_wreg);
     // the stride-2 512-channel downsample stays with st_conv (measured slower there)
     if (dtype == ST_BF16 && k == 1 && p == 0 && !(s == 2 && cin == 512)) {
-      c.ntw = s == 1 ? st_conv1x1_astat_supported(cin, cout) : 0;          // conv3 of layer3 / layer4: activation-stationary kernel
+      c.ntw = use_astat(c) ? st_conv1x1_astat_supported(cin, cout) : 0;    // conv3 of layer3: activation-stationary kernel
       if (c.ntw == 0) c.ntw = st_conv1x1_wreg_supported(cin, cout);
       if (c.ntw == 0) c.ntw = st_conv1x1_kstream_supported(cin, cout);     // 1024 / 2048 input channels: the K-streaming kernel
       if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * cin; }
@@ -312,13 +316,15 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       g.in_stats_replicas = in_ci >= 0 ? tab.rep[in_ci] : 0;
       g.scale = d.scale; g.shift = d.shift; g.relu = d.relu;
       if (train) {
+        // four replicas: the statistics leave a workgroup as full-wave atomics over consecutive channels (block_stats_flush), so the
+        // same-address queue is what is left to spread -- and every consumer adds the replicas up in its prologue (cheap at 4)
         int rep = 1;
-        while (rep < 16 && (rep * 2) * 2 * c.cout <= kStatsRepFloats) rep *= 2;
+        while (rep < 4 && (rep * 2) * 2 * c.cout <= kStatsRepFloats) rep *= 2;
         stats_used -= tab.rep[ci] * 2 * c.cout;
         tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
       }
-      if (c.stride == 1 && st_conv1x1_astat_supported(c.cin, c.cout)) {
+      if (use_astat(c)) {
         if (st_conv1x1_astat(&g, stream)) return 1;
       } else if (c.cin > 512) {
         ST_CHECK(!g.in_stats, "st_resnet_forward: the long-K pointwise kernel has no input transform");
@@ -336,7 +342,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       if (train) {
         int rep = 1;
         const long items = (long)B * ((hin * (win + 2) + 223) / 224);         // ~ workgroups along M
-        while (rep < 16 && items / (rep * 2) >= 4 && (rep * 2) * 2 * c.cout <= kStatsRepFloats) rep *= 2;
+        while (rep < 4 && items / (rep * 2) >= 4 && (rep * 2) * 2 * c.cout <= kStatsRepFloats) rep *= 2;
         stats_used -= tab.rep[ci] * 2 * c.cout;                                // re-plan this layer's replicas
         tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ST_BF16, ST_F32, BnActDesc, Conv1x1WregDesc, Conv3x3ImgDesc, ConvDesc, check, lib
+from ._lib import ST_BF16, ST_F32, BnActDesc, Conv1x1KfuseDesc, Conv1x1WregDesc, Conv3x3ImgDesc, ConvDesc, check, lib
 
 _DT = {torch.float32: ST_F32, torch.bfloat16: ST_BF16}
 
@@ -261,6 +261,21 @@ def conv1x1_wreg(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=Non
         d.in_stats_replicas = int(in_bn.get("replicas", 0))
     check(lib().st_conv1x1_wreg(C.byref(d), _stream()), "st_conv1x1_wreg")
     return out
+
+
+def conv1x1_kfuse(raw, identity, w_frag, bn, stats=None, stats_replicas=0, x_out=None, out=None):
+    """st_conv1x1_kfuse: x = relu(bn(raw) + identity) (written to x_out), y = conv1x1(x) (1024 -> 256).  bn = dict(stats, gamma, beta,
+    count[, eps, replicas]).  Returns (x_out, y)."""
+    _dev(raw, identity, w_frag, stats, x_out, out, bn["stats"], bn["gamma"], bn["beta"])
+    rows = raw.numel() // raw.shape[-1]
+    if x_out is None:
+        x_out = torch.empty_like(raw)
+    if out is None:
+        out = torch.empty(*raw.shape[:-1], 256, device=raw.device, dtype=torch.bfloat16)
+    d = Conv1x1KfuseDesc(_p(raw), _p(identity), _p(x_out), _p(w_frag), _p(out), _p(stats), int(stats_replicas), _p(bn["stats"]), _p(bn["gamma"]),
+                         _p(bn["beta"]), float(bn["count"]), float(bn.get("eps", 1e-5)), int(bn.get("replicas", 0)), rows, raw.shape[-1], 256)
+    check(lib().st_conv1x1_kfuse(C.byref(d), _stream()), "st_conv1x1_kfuse")
+    return x_out, out
 
 
 def conv1x1_astat_supported(Cin, N):

@@ -276,3 +276,33 @@ def test_conv1x1_astat_matches_conv2d_igemm_and_separate_bn_pass(case):
     y2 = ops.conv1x1_astat(xd, wf, N, scale=sc.cuda(), shift=sh.cuda(), relu=True)
     ref2 = F.relu(ref * sc + sh)
     assert (y2.float().cpu() - ref2).abs().max().item() <= 1.5e-2 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("rows_shape", [(4, 14, 14), (1, 9, 13), (3, 7, 5)])
+def test_conv1x1_kfuse_equals_bn_act_then_kstream(rows_shape):
+    """st_conv1x1_kfuse = the block-end normalise pass (relu(bn3(raw) + identity)) + conv1 of the next block in one kernel: x_out must
+    equal st_bn_act's output bit for bit (same coefficients, same rounding point), y the K-streaming kernel's on that x."""
+    ops = _ops()
+    B, H, W = rows_shape
+    C, N = 1024, 256
+    g = torch.Generator().manual_seed(B * H + W)
+    raw = (torch.randn(B, H, W, C, generator=g) * 1.3 + 0.1).bfloat16().cuda()
+    ident = torch.relu(torch.randn(B, H, W, C, generator=g)).bfloat16().cuda()
+    w = (torch.randn(N, C, 1, 1, generator=g) / np.sqrt(C)).bfloat16().float()
+    wf = ops.pack_conv_weight_frag(w.cuda(), 4)
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    r2 = raw.float().reshape(-1, C)
+    stats = torch.cat([r2.sum(0), (r2 * r2).sum(0)]).contiguous()
+    rep = torch.zeros(4, 2 * C, device="cuda"); rep[3] = stats
+    n = float(B * H * W)
+    x_ref = ops.bn_act(raw, gam, bet, stats=stats, count=n, relu=True, res=ident)
+    s0 = torch.zeros(2 * N, device="cuda")
+    y_ref = ops.conv1x1_kstream(x_ref, wf, N, stats=s0)
+    s1 = torch.zeros(2, 2 * N, device="cuda")
+    x, y = ops.conv1x1_kfuse(raw, ident, wf, dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=4), stats=s1, stats_replicas=2)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x_ref)
+    assert torch.equal(y, y_ref)
+    np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s0.cpu().numpy(), rtol=1e-4, atol=1e-2)
+    ref = F.conv2d(x_ref.float().cpu().permute(0, 3, 1, 2), w, None, 1, 0).permute(0, 2, 3, 1)
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
