@@ -102,7 +102,8 @@ typedef struct {
   int B, H, W, C, N;
   int in_stats_replicas;   /* 0/1: in_stats is [2C]; R > 1: [R][2C], summed by the kernel (no reduction launch in between) */
 } st_conv3x3_img_desc;
-/* > 0: supported, the value is the `ntw` the weights must be packed with; 0: use st_conv */
+/* > 0: supported, the value is the LAYOUT CODE the weights must be packed with (st_pack_conv_weight_frag's `ntw` argument:
+ * low byte = 16-channel tiles per wave, bits 8.. = channel halves of the K order); 0: use st_conv */
 int st_conv3x3_img_supported(int H, int W, int C, int N);
 int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream);
 /* ------------------------------------------------------------------------------------

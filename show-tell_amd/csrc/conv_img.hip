@@ -63,11 +63,18 @@ __device__ __forceinline__ void block_stats_flush(const float (&es)[NC], const f
   for (int t = tid; t < 2 * BNLOC; t += 256) atomicAdd(sdst + (t < BNLOC ? chan0 + t : N + chan0 + t - BNLOC), sred[t]);
 }
 
+__device__ __forceinline__ void bn_relu_chunk(u32x4& v, const float* sc, const float* sh);
+
 // C input = output-side channel count of the fill (input channels); TM 16-position tiles per band; NTW 16-channel tiles per wave
-template <int C, int TM, int NTW>
+// HALVES = 2 (C = 256): the band is staged in two channel halves and K runs (half, tap, channel) -- half 0 is filled before the
+// K loop, half 1's transform + LDS writes ride one 16-byte chunk per K-step under the first half's MFMAs (its loads were issued
+// with half 0's), one barrier between the halves: 4 us of the 7.8 us fill leave the critical path.  The fragment-major filters
+// carry the same K order (layout code of st_conv3x3_img_supported).
+template <int C, int TM, int NTW, int HALVES, bool AFFINE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_img_kernel(ImgArgs a) {
   constexpr int PIX = 2 * C + 32;            // bytes per LDS pixel row
   constexpr int CS = C / 32;                 // k-steps per filter tap
+  constexpr int CSH = CS / HALVES;           // ... per channel half
   constexpr int KS = 9 * CS;                 // k-steps in all
   constexpr int CH8 = C / 8;                 // 16-byte chunks per pixel
   constexpr int PSTEP = 256 / CH8;           // pixels per fill pass of the workgroup
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int r16 = lane & 15, q4 = lane >> 4;
   const int T0 = (nb * 4 + wid) * NTW;                              // first 16-channel tile of this wave
   const u32x4* wl = reinterpret_cast<const u32x4*>(a.w) + lane;     // fragment (T, ks) = wl[(T * KS + ks) * 64]
-  constexpr int WQ = ALLW ? KS : CS;
+  constexpr int WQ = ALLW ? KS : CS;                               // (HALVES = 2: two taps of lead)
   u32x4 wq[WQ][NTW];
 #pragma unroll
   for (int s = 0; s < WQ; ++s)
@@ -104,6 +111,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---- fill: padded band [rows + 2][Wp] (+ everything a discarded position may touch, zeroed) ---------------------
   // Every global load of the band is in flight before the first LDS write; the producer's BatchNorm coefficients are
   // derived meanwhile (replicated statistics are summed here: no separate reduction launch).
+  constexpr int CHH = CH8 / 2, U2 = 19;                            // HALVES == 2: chunks per pixel per half; passes of 16 pixels (<= 297 LDS pixels)
+  u32x4 v1[HALVES == 2 ? U2 : 1]; bool ok1[HALVES == 2 ? U2 : 1];  // second channel half: loaded now, written under the first half's MFMAs
+  float sc1[8], sh1[8];
+  const int cch2 = tid % CHH, pp2 = tid / CHH;
+  const bool xf_ = a.in_stats != nullptr;
+  if constexpr (HALVES == 2) {
+    const int total = 16 * TM + 2 * Wp + 2;
+    float* coef = reinterpret_cast<float*>(smem + (size_t)total * PIX);
+    const bf16_t* ximg = a.x + (size_t)img * a.H * a.W * C + cch2 * 8;
+    u32x4 v0[U2];
+    int pr = pp2 / Wp, pc = pp2 - pr * Wp;
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      const int hi = r0 - 1 + pr, wi = pc - 1;
+      ok1[u] = pr < rows + 2 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      // unconditional loads from a clamped in-image address, zeroed by a select: a load under a branch drains vmcnt at the join and
+      // the 38 loads of the fill would go out one round trip at a time
+      const int hc = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wc = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+      v0[u] = *reinterpret_cast<const u32x4*>(ximg + (size_t)(hc * a.W + wc) * C);
+      v1[u] = *reinterpret_cast<const u32x4*>(ximg + (size_t)(hc * a.W + wc) * C + C / 2);
+      if (!ok1[u]) { v0[u] = u32x4{0u, 0u, 0u, 0u}; v1[u] = u32x4{0u, 0u, 0u, 0u}; }
+      pc += 16;
+      while (pc >= Wp) { pc -= Wp; ++pr; }
+    }
+    float sc0[8], sh0[8];
+    if (xf_) {
+      const float inv = 1.0f / a.in_count;
+      for (int c = tid; c < C; c += 256) {
+        float sm = 0.f, sq = 0.f;
+        for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * C + c]; sq += a.in_stats[(size_t)r * 2 * C + C + c]; }
+        const float mean = sm * inv;
+        const float var = fmaxf(sq * inv - mean * mean, 0.f);
+        const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
+        coef[c] = scv; coef[C + c] = a.in_beta[c] - mean * scv;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc0[e] = coef[cch2 * 8 + e]; sh0[e] = coef[C + cch2 * 8 + e];
+        sc1[e] = coef[C / 2 + cch2 * 8 + e]; sh1[e] = coef[C + C / 2 + cch2 * 8 + e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      if (xf_ && ok1[u]) bn_relu_chunk(v0[u], sc0, sh0);
+      if (pp2 + 16 * u < total) *reinterpret_cast<u32x4*>(smem + (size_t)(pp2 + 16 * u) * PIX + cch2 * 16) = v0[u];
+    }
+  } else
   {
     const int cch = tid % CH8;
     float sc[8], sh[8];
@@ -122,8 +177,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int hi = r0 - 1 + pr, wi = pc - 1;
         ok[u] = pr < rows + 2 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
         dst[u] = pp + u * PSTEP < total ? (pp + u * PSTEP) * PIX + cch * 16 : -1;
-        v[u] = u32x4{0u, 0u, 0u, 0u};
-        if (ok[u]) v[u] = *reinterpret_cast<const u32x4*>(ximg + (size_t)(hi * a.W + wi) * C);
+        const int hc = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wc = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+        v[u] = *reinterpret_cast<const u32x4*>(ximg + (size_t)(hc * a.W + wc) * C);     // unconditional (clamped), zeroed by a select
+        if (!ok[u]) v[u] = u32x4{0u, 0u, 0u, 0u};
         pc += PSTEP;
         while (pc >= Wp) { pc -= Wp; ++pr; }
       }
@@ -172,7 +228,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // its filter registers for step s + WQ.  The waits the compiler inserts are then counted (lgkmcnt(TM), vmcnt((WQ-1) NTW)).
   constexpr int TH = TM > 7 ? 7 : TM;                               // tiles addressed from the first base register (16-bit ds offsets)
   const char* abase = smem + r16 * PIX + q4 * 16;
-  auto read_a = [&](u32x4 (&fa)[TM], int tap, int cs) {
+  // K-step s -> (channel half, tap, 32-channel step inside the half): s = (half * 9 + tap) * CSH + cs
+  auto read_a = [&](u32x4 (&fa)[TM], int s) {
+    const int half = s / (9 * CSH), tap = (s / CSH) % 9, cs = half * CSH + s % CSH;
     const char* ab = abase + ((tap / 3) * Wp + tap % 3) * PIX;
     const char* ab2 = ab + TH * 16 * PIX;
 #pragma unroll
@@ -180,12 +238,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       fa[i] = i < TH ? *reinterpret_cast<const u32x4*>(ab + i * 16 * PIX + cs * 64) : *reinterpret_cast<const u32x4*>(ab2 + (i - TH) * 16 * PIX + cs * 64);
   };
   u32x4 fa0[TM], fa1[TM];
-  read_a(fa0, 0, 0);
-#pragma unroll
+  read_a(fa0, 0);
+#pragma clang loop unroll(full)
   for (int s = 0; s < KS; ++s) {
     u32x4 (&cur)[TM] = (s & 1) ? fa1 : fa0;
     u32x4 (&nxt)[TM] = (s & 1) ? fa0 : fa1;
-    if (s + 1 < KS) read_a(nxt, (s + 1) / CS, (s + 1) % CS);
+    constexpr int SPLIT = HALVES == 2 ? KS / 2 : -1;               // first K-step that reads the second channel half
+    if (s + 1 < KS && s + 1 != SPLIT) read_a(nxt, s + 1);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -194,7 +253,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int j = 0; j < NTW; ++j) wq[s % WQ][j] = wl[((size_t)(T0 + j) * KS + s + WQ) * 64];
     }
+    if constexpr (HALVES == 2) {
+      if (s < U2) {                                                 // this K-step's share of the second half: one chunk per thread
+        if (xf_ && ok1[s]) bn_relu_chunk(v1[s], sc1, sh1);
+        if (pp2 + 16 * s < 16 * TM + 2 * Wp + 2) *reinterpret_cast<u32x4*>(smem + (size_t)(pp2 + 16 * s) * PIX + C + cch2 * 16) = v1[s];
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HALVES == 2) {
+      if (s + 1 == SPLIT) { __syncthreads(); read_a(nxt, s + 1); }   // the second half is complete in LDS for every wave
+    }
   }
 
   IMG_STAMP(3);
@@ -204,10 +272,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float es[NC], ess[NC], scv[NC], shv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; scv[c] = 1.f; shv[c] = 0.f; }
-  const bool affine = a.scale != nullptr;
-  if (affine) {
+  if constexpr (AFFINE) {   // eval-mode scale / shift: loaded and waited for HERE (a first use under the per-tile branch put vmcnt(0) into
+                            // every tile of the epilogue, train mode included: each tile's stores were drained before the next tile)
 #pragma unroll
     for (int c = 0; c < NC; ++c) { scv[c] = a.scale[cb + c]; shv[c] = a.shift[cb + c]; }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(scv[c]), "+v"(shv[c]));
   }
   int ho = r0, wo = r16;
   while (wo >= Wp) { wo -= Wp; ++ho; }
@@ -223,13 +293,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
 #pragma unroll
       for (int c = 0; c < NC; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
-      if (affine) {
+      if constexpr (AFFINE) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) v[c] = v[c] * scv[c] + shv[c];
-      }
-      if (a.relu) {
+        if (a.relu) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
+          for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
+        }
       }
       bf16_t* dst = yimg + (size_t)(ho * a.W + wo) * a.N;
       if constexpr (NTW == 1) {
@@ -967,17 +1037,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // out[((T * KS + ks) * 64 + lane) * 8 + j], T = 16-channel tile, ks = 32-deep K step (k = tap * Cin + c), lane = (q4, r16):
 // MFMA row r16 of tile T is output channel ch(T, r16) = (T / NTW) * 16 NTW + 4 NTW (r16 / 4) + 4 (T % NTW) + r16 % 4
 // (so that a lane's accumulators of a wave's NTW tiles are 4 NTW consecutive channels), k = 32 ks + 8 q4 + j.
-__global__ void pack_frag_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int KH, int KW, int ntw) {
+__global__ void pack_frag_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int KH, int KW, int ntw, int halves) {
   const long total = (long)Cout * KH * KW * Cin;
   const int KS = KH * KW * Cin / 32;
+  const int CH = Cin / halves;                      // halves = 2: K runs (channel half, tap, channel inside the half)
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int j = idx & 7, lane = (idx >> 3) & 63;
     const long f = idx >> 9;
     const int ks = (int)(f % KS), T = (int)(f / KS);
     const int r16 = lane & 15, q4 = lane >> 4;
     const int ch = (T / ntw) * 16 * ntw + 4 * ntw * (r16 >> 2) + 4 * (T % ntw) + (r16 & 3);
-    const int k = 32 * ks + 8 * q4 + j;
-    const int tap = k / Cin, c = k - tap * Cin;
+    const int kk = 32 * ks + 8 * q4 + j;            // position in the kernel's K order
+    const int half = kk / (KH * KW * CH), rem = kk - half * KH * KW * CH;
+    const int tap = rem / CH, c = half * CH + rem - tap * CH;
     const int kh = tap / KW, kw = tap - kh * KW;
     out[idx] = (bf16_t)w[(((long)ch * Cin + c) * KH + kh) * KW + kw];
   }
@@ -995,22 +1067,26 @@ inline bool img_cfg(int C, int N, ImgCfg* c) {
   return false;
 }
 
-template <int C, int TM, int NTW>
-int launch_img(const ImgArgs& a, int lds, hipStream_t st, double flops) {
+template <int C, int TM, int NTW, int HALVES, bool AFFINE>
+int launch_img_(const ImgArgs& a, int lds, hipStream_t st, double flops) {
   static int attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && attr_set[dev] < lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel<C, TM, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel<C, TM, NTW, HALVES, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 160 * 1024;
   }
   StProfScope prof(C == 64 ? 8 : C == 128 ? 9 : C == 256 ? 10 : 11, flops, st);
-  hipLaunchKernelGGL((conv3x3_img_kernel<C, TM, NTW>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_img_kernel<C, TM, NTW, HALVES, AFFINE>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
 }
 
+template <int C, int TM, int NTW, int HALVES>
+int launch_img(const ImgArgs& a, int lds, hipStream_t st, double flops) {
+  return a.scale ? launch_img_<C, TM, NTW, HALVES, true>(a, lds, st, flops) : launch_img_<C, TM, NTW, HALVES, false>(a, lds, st, flops);
+}
 }  // namespace
 
 // > 0: the NTW (16-channel tiles per wave) of the fragment-major weight layout this geometry runs with; 0: not supported
@@ -1020,7 +1096,7 @@ extern "C" int st_conv3x3_img_supported(int H, int W, int C, int N) {
   const int Wp = W + 2;
   if (H < 1 || W < 1 || 16 * c.tm < Wp) return 0;                  // at least one output row per band
   const long lds = (long)(16 * c.tm + 2 * Wp + 2) * (2 * C + 32) + 2 * C * (long)sizeof(float);
-  return lds <= 160 * 1024 ? c.ntw : 0;
+  return lds <= 160 * 1024 ? (c.ntw | (C == 256 ? 2 << 8 : 0)) : 0;   // layout code: ntw | K-order halves << 8
 }
 
 extern "C" int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream) {
@@ -1029,7 +1105,7 @@ extern "C" int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream) {
   ST_CHECK(st_conv3x3_img_supported(d->H, d->W, d->C, d->N) > 0 && img_cfg(d->C, d->N, &c),
            "st_conv3x3_img: unsupported geometry H=%d W=%d C=%d N=%d", d->H, d->W, d->C, d->N);
   ST_CHECK(d->B > 0 && (long)d->B * d->H * d->W * (d->C > d->N ? d->C : d->N) < (1L << 31), "st_conv3x3_img: bad batch");
-  ST_CHECK((d->scale == nullptr) == (d->shift == nullptr), "st_conv3x3_img: scale and shift go together");
+  ST_CHECK((d->scale == nullptr) == (d->shift == nullptr) && (d->scale || !d->relu), "st_conv3x3_img: scale, shift (and relu) go together");
   ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f), "st_conv3x3_img: input transform needs gamma, beta, count");
   ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->in_stats_replicas >= 0 && d->in_stats_replicas <= 1024, "st_conv3x3_img: bad stats_replicas");
   ImgArgs a;
@@ -1045,10 +1121,10 @@ extern "C" int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * d->B * d->H * d->W * (double)d->N * 9.0 * d->C;
   switch (d->C) {
-    case 64:  return launch_img<64, 15, 1>(a, lds, st, flops);
-    case 128: return launch_img<128, 14, 2>(a, lds, st, flops);
-    case 256: return launch_img<256, 14, 2>(a, lds, st, flops);
-    case 512: return launch_img<512, 4, 2>(a, lds, st, flops);
+    case 64:  return launch_img<64, 15, 1, 1>(a, lds, st, flops);
+    case 128: return launch_img<128, 14, 2, 1>(a, lds, st, flops);
+    case 256: return launch_img<256, 14, 2, 2>(a, lds, st, flops);
+    case 512: return launch_img<512, 4, 2, 1>(a, lds, st, flops);
   }
   st_set_error("st_conv3x3_img: no kernel for C=%d", d->C);
   return 1;
@@ -1282,12 +1358,14 @@ extern "C" int st_conv1x1_kstream(const st_conv1x1_wreg_desc* d, void* stream) {
 
 extern "C" int st_pack_conv_weight_frag(const float* w, void* out, int Cout, int Cin, int KH, int KW, int ntw, void* stream) {
   ST_CHECK(w && out, "st_pack_conv_weight_frag: null pointer");
-  ST_CHECK(ntw >= 1 && ntw <= 16 && Cout % (16 * ntw) == 0 && (KH * KW * Cin) % 32 == 0 && Cin % 8 == 0,
+  const int halves = (ntw >> 8) > 0 ? (ntw >> 8) : 1;           // layout code of the *_supported queries: ntw | K-order halves << 8
+  ntw &= 0xff;
+  ST_CHECK(ntw >= 1 && ntw <= 16 && Cout % (16 * ntw) == 0 && (KH * KW * Cin) % 32 == 0 && Cin % 8 == 0 && (halves == 1 || (halves == 2 && Cin % 64 == 0)),
            "st_pack_conv_weight_frag: Cout=%d must be a multiple of %d and Cin=%d of 8 (K %% 32 == 0)", Cout, 16 * ntw, Cin);
   const long total = (long)Cout * KH * KW * Cin;
   long grid = (total + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
-                     reinterpret_cast<bf16_t*>(out), Cout, Cin, KH, KW, ntw);
+                     reinterpret_cast<bf16_t*>(out), Cout, Cin, KH, KW, ntw, halves);
   ST_LAUNCH_CHECK();
   return 0;
 }
