@@ -262,7 +262,7 @@ def main():
         prefixes = {0: ("igemm_kernel<bf16,128,128,2,4,", "igemm_s3b_kernel")}
         for i_, c_ in enumerate((64, 128, 256, 512)):          # csrc/conv_img.hip: one slot per kernel symbol (csrc/prof.h)
             names[8 + i_] = "conv3x3_img_kernel<%d,...> (image-resident 3x3, csrc/conv_img.hip)" % c_
-            prefixes[8 + i_] = ("conv3x3_img_kernel<%d," % c_,)
+            prefixes[8 + i_] = ("conv3x3_img_kernel<%d," % c_, "conv3x3_img_kernel_occ2<%d," % c_)
             names[12 + i_] = "conv1x1_wreg_kernel<%d,...> (pointwise, filter slice in registers, csrc/conv_img.hip)" % c_
             prefixes[12 + i_] = ("conv1x1_wreg_kernel<%d," % c_,)
         for i_, c_ in enumerate((1024, 2048)):

@@ -71,7 +71,7 @@ __device__ __forceinline__ void bn_relu_chunk(u32x4& v, const float* sc, const f
 // with half 0's), one barrier between the halves: 4 us of the 7.8 us fill leave the critical path.  The fragment-major filters
 // carry the same K order (layout code of st_conv3x3_img_supported).
 template <int C, int TM, int NTW, int HALVES, bool AFFINE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_img_kernel(ImgArgs a) {
+__device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
   constexpr int PIX = 2 * C + 32;            // bytes per LDS pixel row
   constexpr int CS = C / 32;                 // k-steps per filter tap
   constexpr int CSH = CS / HALVES;           // ... per channel half
@@ -322,6 +322,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   IMG_STAMP(4);
 #undef IMG_STAMP
+}
+
+// Two entry points over one body: the 128..512-channel forms want the whole register file of a SIMD for ONE wave (waves_per_eu(1, 1)
+// lets the allocator use it); the 64-channel form (202 registers, 58 KB of LDS) runs two workgroups per CU -- under (1, 1) it was
+// held to one and took 7 rounds instead of 3.5 on the 56 x 56 layers.
+template <int C, int TM, int NTW, int HALVES, bool AFFINE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_img_kernel(ImgArgs a) {
+  conv3x3_img_body<C, TM, NTW, HALVES, AFFINE>(a);
+}
+template <int C, int TM, int NTW, int HALVES, bool AFFINE>
+__global__ __launch_bounds__(256, 2) void conv3x3_img_kernel_occ2(ImgArgs a) {
+  conv3x3_img_body<C, TM, NTW, HALVES, AFFINE>(a);
 }
 
 // =====================================================================================================================
@@ -1073,11 +1085,13 @@ int launch_img_(const ImgArgs& a, int lds, hipStream_t st, double flops) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && attr_set[dev] < lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel<C, TM, NTW, HALVES, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (C == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel_occ2<C, TM, NTW, HALVES, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel<C, TM, NTW, HALVES, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 160 * 1024;
   }
   StProfScope prof(C == 64 ? 8 : C == 128 ? 9 : C == 256 ? 10 : 11, flops, st);
-  hipLaunchKernelGGL((conv3x3_img_kernel<C, TM, NTW, HALVES, AFFINE>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
+  if constexpr (C == 64) hipLaunchKernelGGL((conv3x3_img_kernel_occ2<C, TM, NTW, HALVES, AFFINE>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((conv3x3_img_kernel<C, TM, NTW, HALVES, AFFINE>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
