@@ -142,7 +142,8 @@ typedef struct {
 int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream);
 /* The activation-stationary sibling for (C, N) = (256, 1024) / (512, 2048) (conv3 of the layer3 / layer4 Bottlenecks): a
  * workgroup keeps its 112 x C rows in LDS (producer's BatchNorm + ReLU applied once per element) and walks all N output
- * channels barrier-free.  Same descriptor (ntw = 4 weights), stride 1, residual NULL. */
+ * channels barrier-free, the epilogue of one 128-channel chunk under the next chunk's MFMAs.  Same descriptor (weights packed with the
+ * layout code st_conv1x1_astat_supported returns), stride 1, residual NULL. */
 int st_conv1x1_astat_supported(int C, int N);
 int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream);
 

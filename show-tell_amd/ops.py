@@ -283,7 +283,7 @@ def conv1x1_astat_supported(Cin, N):
 
 
 def conv1x1_astat(x, w_frag, N, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, in_bn=None, out=None):
-    """Activation-stationary 1x1 conv (st_conv1x1_astat): (C, N) in {(256, 1024), (512, 2048)}, w_frag = pack_conv_weight_frag(w, 4)."""
+    """Activation-stationary 1x1 conv (st_conv1x1_astat): (C, N) in {(256, 1024), (512, 2048)}, w_frag = pack_conv_weight_frag(w, conv1x1_astat_supported(C, N))."""
     _dev(x, w_frag, stats, scale, shift, out)
     B, H, W, Cc = x.shape
     if out is None:

@@ -242,11 +242,11 @@ AS_CASES = [(4, 14, 14, 256, 1024), (5, 7, 7, 512, 2048), (1, 3, 5, 256, 1024)]
 def test_conv1x1_astat_matches_conv2d_igemm_and_separate_bn_pass(case):
     ops = _ops()
     B, H, W, C, N = case
-    assert ops.conv1x1_astat_supported(C, N) == 4 and ops.conv1x1_astat_supported(256, 512) == 0
+    assert ops.conv1x1_astat_supported(C, N) == 2 and ops.conv1x1_astat_supported(256, 512) == 0
     x, w = _pw_data(case + (1,))
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, 0).permute(0, 2, 3, 1).contiguous()
     xd = x.cuda()
-    wf = ops.pack_conv_weight_frag(w.cuda(), 4)
+    wf = ops.pack_conv_weight_frag(w.cuda(), ops.conv1x1_astat_supported(C, N))
     R = 4
     st = torch.zeros(R, 2 * N, device="cuda")
     y = ops.conv1x1_astat(xd, wf, N, stats=st, stats_replicas=R)

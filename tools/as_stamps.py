@@ -7,7 +7,7 @@ from showtell_amd._lib import lib
 B, h, c, n = 128, 14, 256, 1024
 xs = [torch.randn(B, h, h, c, device="cuda").bfloat16() for _ in range(3)]
 w = torch.randn(n, c, 1, 1, device="cuda") / c ** 0.5
-wf = ops.pack_conv_weight_frag(w, 4)
+wf = ops.pack_conv_weight_frag(w, ops.conv1x1_astat_supported(c, n))
 st = torch.zeros(4, 2 * n, device="cuda")
 x2 = xs[0].float().reshape(-1, c)
 ist = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).contiguous()
@@ -31,7 +31,7 @@ print(f"3 launches: {e0.elapsed_time(e1) * 1e3 / 3:.1f} us each")
 s = buf.cpu().numpy().reshape(-1, 8)
 s = s[s[:, 0] != 0].astype(np.float64)
 d = np.diff(s[:, :6], axis=1) / 2400.0
-for i, nm in enumerate(["filter prefetch + fill", "chunk 0 (+ epilogue)", "chunk 1", "chunks 2-3", "statistics flush"]):
+for i, nm in enumerate(["filter prefetch + fill", "chunk 0", "chunks 1-3 (+ epilogues 0-2)", "chunks 4-7 + last epilogue", "statistics flush"]):
     print(f"  {nm:>40}: mean {d[:, i].mean():6.2f} us  p10 {np.percentile(d[:, i], 10):6.2f}  p90 {np.percentile(d[:, i], 90):6.2f}")
 print(f"  wave total {d.sum(1).mean():.2f} us over {len(s)} waves")
 

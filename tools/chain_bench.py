@@ -20,7 +20,7 @@ W2i = [ops.pack_conv_weight_frag(w, ops.conv3x3_img_supported(h, h, 256, 256)) f
 W3f = [torch.randn(1024, 256, 1, 1, device=dev) / 16 for _ in range(NL)]
 W3 = [w.reshape(1024, 256).to(dt) for w in W3f]
 W3i = [ops.pack_conv_weight_frag(w, ops.conv1x1_wreg_supported(256, 1024)) for w in W3f]
-W3a = [ops.pack_conv_weight_frag(w, 4) for w in W3f]
+W3a = [ops.pack_conv_weight_frag(w, ops.conv1x1_astat_supported(256, 1024)) for w in W3f]
 W1f = [w.float().reshape(256, 1024, 1, 1) for w in W1]
 W1k = [ops.pack_conv_weight_frag(w, 4) for w in W1f]
 s1r = torch.zeros(16, 512, device=dev)
