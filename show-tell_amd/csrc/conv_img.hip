@@ -727,10 +727,11 @@ struct AsArgs {
   const float* scale; const float* shift; int relu;
   const float* in_stats; const float* in_gamma; const float* in_beta; float in_count, in_eps; int in_srep;
   int M, N;
+  int Hin, Win, Ho, Wo, stride;  // STRIDED: output row (b, ho, wo) reads input pixel (b, ho * stride, wo * stride)
   unsigned long long* stamps;   // debug (tools/as_stamps.py), normally NULL
 };
 
-template <int K, int NCH, bool AFFINE>
+template <int K, int NCH, bool AFFINE, bool STRIDED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_astat_kernel(AsArgs a) {
   // NCH chunks of 128 output channels (32 per wave, NTW = 2).  TWO accumulator sets alternate by chunk: the epilogue of chunk c-1
   // (accumulator reads, statistics, bf16 packing, stores: ~600 VALU instructions) is spread over the K-steps of chunk c, one
@@ -770,11 +771,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {
     const int cch = tid % CH8, lrow = tid / CH8;
     u32x4 v[NL];
+    if constexpr (STRIDED) {
+      // (image, row, column) of this thread's first output row by division, the next ones by carry (RPP < Wo on every layer
+      // routed here; the loop form is right for any RPP)
+      int m0 = bm * BM + lrow;
+      m0 = m0 < a.M ? m0 : a.M - 1;
+      const int hw = a.Ho * a.Wo;
+      int b = m0 / hw, rem = m0 - b * hw, ho = rem / a.Wo, wo = rem - ho * a.Wo, m = m0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      int m = bm * BM + lrow + i * RPP;
-      m = m < a.M ? m : a.M - 1;
-      v[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)m * K + cch * 8);
+      for (int i = 0; i < NL; ++i) {
+        const long src = ((long)b * a.Hin + ho * a.stride) * a.Win + wo * a.stride;
+        v[i] = *reinterpret_cast<const u32x4*>(a.x + src * K + cch * 8);
+        if (m + RPP < a.M) {                                          // rows past the end re-read the last valid row (never stored)
+          m += RPP; wo += RPP;
+          while (wo >= a.Wo) { wo -= a.Wo; if (++ho == a.Ho) { ho = 0; ++b; } }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        int m = bm * BM + lrow + i * RPP;
+        m = m < a.M ? m : a.M - 1;
+        v[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)m * K + cch * 8);
+      }
     }
     if (a.in_stats) {
       const float inv = 1.0f / a.in_count;
@@ -1293,32 +1312,41 @@ int launch_ks(KsArgs& a, hipStream_t st, double flops) {
 }  // namespace
 
 namespace {
-template <int K, int NCH, bool AFFINE>
-int launch_as_(AsArgs& a, hipStream_t st, double flops) {
+template <int K, int NCH, bool AFFINE, bool STRIDED>
+int launch_as__(AsArgs& a, hipStream_t st, double flops) {
   constexpr int lds = 112 * (2 * K + 32) + 2 * 128 * NCH * 4 + 2 * K * 4;
   static_assert(lds <= 160 * 1024, "activation block does not fit");
   static int attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_astat_kernel<K, NCH, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
   StProfScope prof(K == 256 ? 18 : 19, flops, st);
-  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE>), dim3((a.M + 111) / 112), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED>), dim3((a.M + 111) / 112), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
 }
+template <int K, int NCH, bool STRIDED>
+int launch_as_(AsArgs& a, hipStream_t st, double flops) {
+  return a.scale ? launch_as__<K, NCH, true, STRIDED>(a, st, flops) : launch_as__<K, NCH, false, STRIDED>(a, st, flops);
+}
 }  // namespace
 
-// 2: supported (ntw of the fragment-major weights); 0: not.  (C, N) in {(256, 1024), (512, 2048)}: conv3 of layer3 / layer4.
-extern "C" int st_conv1x1_astat_supported(int K, int N) { return ((K == 256 && N == 1024) || (K == 512 && N == 2048)) ? 2 : 0; }
+// 2: supported (ntw of the fragment-major weights); 0: not.  Stride 1: (C, N) in {(256, 1024), (512, 2048)}, conv3 of layer3 / layer4;
+// stride 2: (256, 512) and (512, 1024), the downsample convs of layer2 / layer3.
+extern "C" int st_conv1x1_astat_supported(int K, int N) {
+  return ((K == 256 && (N == 1024 || N == 512)) || (K == 512 && (N == 2048 || N == 1024))) ? 2 : 0;
+}
 
 extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   ST_CHECK(d && d->x && d->w_frag && d->y, "st_conv1x1_astat: null pointer");
   ST_CHECK(st_conv1x1_astat_supported(d->C, d->N), "st_conv1x1_astat: unsupported geometry C=%d N=%d", d->C, d->N);
-  ST_CHECK(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->stride == 1, "st_conv1x1_astat: bad geometry (stride 1 only)");
+  const bool strided = d->stride > 1;
+  ST_CHECK(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->stride >= 1, "st_conv1x1_astat: bad geometry");
+  ST_CHECK(strided == (d->N == 2 * d->C), "st_conv1x1_astat: C=%d N=%d comes with stride %s", d->C, d->N, d->N == 2 * d->C ? "> 1" : "1");
   ST_CHECK((d->scale == nullptr) == (d->shift == nullptr) && (d->scale || !d->relu), "st_conv1x1_astat: scale, shift (and relu) go together");
   ST_CHECK(!d->residual, "st_conv1x1_astat: no residual input (use st_conv)");
   ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f), "st_conv1x1_astat: input transform needs gamma, beta, count");
@@ -1328,13 +1356,15 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   a.stats = d->stats; a.srep = d->stats_replicas; a.scale = d->scale; a.shift = d->shift; a.relu = d->relu;
   a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_count = d->in_count; a.in_eps = d->in_eps;
   a.in_srep = d->in_stats_replicas > 1 ? d->in_stats_replicas : 1;
-  const long M = (long)d->B * d->Hin * d->Win;
+  a.Hin = d->Hin; a.Win = d->Win; a.stride = d->stride;
+  a.Ho = (d->Hin - 1) / d->stride + 1; a.Wo = (d->Win - 1) / d->stride + 1;
+  const long M = (long)d->B * a.Ho * a.Wo;
   ST_CHECK(M < (1L << 31) - 4096, "st_conv1x1_astat: too many rows");
   a.M = (int)M; a.N = d->N; a.stamps = st_debug_stamps_ptr();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)M * d->N * d->C;
-  if (d->C == 256) return a.scale ? launch_as_<256, 8, true>(a, st, flops) : launch_as_<256, 8, false>(a, st, flops);
-  return a.scale ? launch_as_<512, 16, true>(a, st, flops) : launch_as_<512, 16, false>(a, st, flops);
+  if (d->C == 256) return strided ? launch_as_<256, 4, true>(a, st, flops) : launch_as_<256, 8, false>(a, st, flops);
+  return strided ? launch_as_<512, 8, true>(a, st, flops) : launch_as_<512, 16, false>(a, st, flops);
 }
 
 // conv1 (C -> 256, C = 1024) fused with the previous block's end; see st_conv1x1_kfuse_desc in the header

@@ -22,10 +22,15 @@
 
 struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; int korder; size_t woff_frag; int ntw; };   // woff_frag: fragment-major copy for st_conv3x3_img (ntw > 0)
 struct BlockL { int c1, c2, c3, ds; int stride; };
-// The activation-stationary pointwise kernel (one workgroup per 112 rows) takes the 256 -> 1024 conv3 of layer3; layer4's 512 -> 2048
+// The activation-stationary pointwise kernel (one workgroup per 112 rows) takes the 256 -> 1024 conv3 of layer3 and the stride-2
+// downsample convs of layer2 / layer3 (256 -> 512, 512 -> 1024: many output-channel slices per input row); layer4's 512 -> 2048
 // has only 49 rows per image (56 workgroups at B = 128: measured 63 us against 32 on st_conv1x1_wreg) and stays there.  Static per
 // layer: the fragment-major copy is packed for ONE kernel's channel permutation (ntw).
-static inline bool use_astat(const ConvL& c) { return c.k == 1 && c.stride == 1 && c.cin == 256 && c.cout == 1024; }  // indices into convs (c3 = -1 for basic blocks, ds = -1 if none)
+static inline bool use_astat(const ConvL& c) {
+  if (c.k != 1) return false;
+  if (c.stride == 1) return c.cin == 256 && c.cout == 1024;
+  return c.stride == 2 && ((c.cin == 256 && c.cout == 512) || (c.cin == 512 && c.cout == 1024));   // downsample convs of layer2 / layer3
+}
 
 struct BnTable { int n; int end[160]; float count[160]; int soff[160]; int rep[160]; };   // soff: float offset of the layer's [rep][2C] statistics
 struct PendingUpdate { BnTable tab; const float* stats; };
@@ -133,9 +138,9 @@ extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
       if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * 9 * cin; }
     }
     // pointwise layers with <= 512 input channels: fragment-major copy for the register-resident-filter kernel (st_conv1x1_wreg);
-    // the stride-2 512-channel downsample stays with st_conv (measured slower there)
-    if (dtype == ST_BF16 && k == 1 && p == 0 && !(s == 2 && cin == 512)) {
-      c.ntw = use_astat(c) ? st_conv1x1_astat_supported(cin, cout) : 0;    // conv3 of layer3: activation-stationary kernel
+    // a stride-2 512-channel layer the activation-stationary kernel does not take stays with st_conv (measured slower on wreg)
+    if (dtype == ST_BF16 && k == 1 && p == 0 && (use_astat(c) || !(s == 2 && cin == 512))) {
+      c.ntw = use_astat(c) ? st_conv1x1_astat_supported(cin, cout) : 0;    // conv3 of layer3, downsample of layer2 / layer3
       if (c.ntw == 0) c.ntw = st_conv1x1_wreg_supported(cin, cout);
       if (c.ntw == 0) c.ntw = st_conv1x1_kstream_supported(cin, cout);     // 1024 / 2048 input channels: the K-streaming kernel
       if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * cin; }

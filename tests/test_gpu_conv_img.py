@@ -235,26 +235,27 @@ def test_conv1x1_kstream_matches_conv2d_and_igemm(case):
 
 
 # ---- st_conv1x1_astat: (B, H, W, C, N) -----------------------------------------------------------------------------------
-AS_CASES = [(4, 14, 14, 256, 1024), (5, 7, 7, 512, 2048), (1, 3, 5, 256, 1024)]
+AS_CASES = [(4, 14, 14, 256, 1024, 1), (5, 7, 7, 512, 2048, 1), (1, 3, 5, 256, 1024, 1),
+            (3, 28, 28, 256, 512, 2), (2, 28, 28, 512, 1024, 2), (5, 9, 7, 256, 512, 2), (1, 1, 3, 512, 1024, 2)]   # stride 2: the downsample convs
 
 
 @pytest.mark.parametrize("case", AS_CASES)
 def test_conv1x1_astat_matches_conv2d_igemm_and_separate_bn_pass(case):
     ops = _ops()
-    B, H, W, C, N = case
-    assert ops.conv1x1_astat_supported(C, N) == 2 and ops.conv1x1_astat_supported(256, 512) == 0
-    x, w = _pw_data(case + (1,))
-    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, 0).permute(0, 2, 3, 1).contiguous()
+    B, H, W, C, N, S = case
+    assert ops.conv1x1_astat_supported(C, N) == 2 and ops.conv1x1_astat_supported(256, 256) == 0
+    x, w = _pw_data(case)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, S, 0).permute(0, 2, 3, 1).contiguous()
     xd = x.cuda()
     wf = ops.pack_conv_weight_frag(w.cuda(), ops.conv1x1_astat_supported(C, N))
     R = 4
     st = torch.zeros(R, 2 * N, device="cuda")
-    y = ops.conv1x1_astat(xd, wf, N, stats=st, stats_replicas=R)
+    y = ops.conv1x1_astat(xd, wf, N, stride=S, stats=st, stats_replicas=R)
     torch.cuda.synchronize()
     scale = ref.abs().max().item()
     assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * scale
     s0 = torch.zeros(2 * N, device="cuda")
-    y0 = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16), 1, 1, 1, 0, stats=s0)
+    y0 = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16), 1, 1, S, 0, stats=s0)
     assert (y.float() - y0.float()).abs().max().item() <= 2.0 ** -7 * scale
     assert (y != y0).float().mean().item() < 0.02
     r2 = ref.reshape(-1, N)
@@ -267,13 +268,13 @@ def test_conv1x1_astat_matches_conv2d_igemm_and_separate_bn_pass(case):
     x2 = xd.float().reshape(-1, C)
     stats = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).contiguous()
     n = float(B * H * W)
-    y_sep = ops.conv1x1_astat(ops.bn_act(xd, gam, bet, stats=stats, count=n, relu=True), wf, N)
+    y_sep = ops.conv1x1_astat(ops.bn_act(xd, gam, bet, stats=stats, count=n, relu=True), wf, N, stride=S)
     rep = torch.zeros(3, 2 * C, device="cuda"); rep[0] = stats
-    y_fused = ops.conv1x1_astat(xd, wf, N, in_bn=dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=3))
+    y_fused = ops.conv1x1_astat(xd, wf, N, stride=S, in_bn=dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=3))
     assert torch.equal(y_sep, y_fused)
     # eval-mode epilogue
     sc, sh = (torch.rand(N, generator=g) + 0.5), torch.randn(N, generator=g) * 0.3
-    y2 = ops.conv1x1_astat(xd, wf, N, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    y2 = ops.conv1x1_astat(xd, wf, N, stride=S, scale=sc.cuda(), shift=sh.cuda(), relu=True)
     ref2 = F.relu(ref * sc + sh)
     assert (y2.float().cpu() - ref2).abs().max().item() <= 1.5e-2 * ref2.abs().max().item()
 
