@@ -129,16 +129,22 @@ int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream);
 int st_conv1x1_kstream_supported(int C, int N);
 int st_conv1x1_kstream(const st_conv1x1_wreg_desc* d, void* stream);
 /* conv1 of a Bottleneck fused with the PREVIOUS block's end (torchvision Bottleneck.forward: out = relu(bn3(conv3(..)) + identity),
- * then the next block's conv1(out); reference cnn.py:46), train mode, C = 1024 -> N = 256 (layer3):
- *   x_out = relu(batchnorm(raw; f_stats, f_gamma, f_beta) + identity)   -- written once, it is the next identity
- *   y     = x_out (*) w_frag (1x1, ntw = 4 fragment-major weights),  stats += [sum | sumsq] of y
- * raw / identity / x_out: [rows][1024] bf16, y: [rows][256] bf16.  Replaces one st_bn_act pass + st_conv1x1_kstream. */
+ * then the next block's conv1(out); reference cnn.py:46), train mode:
+ *   x_out = relu(batchnorm(raw; f_stats, f_gamma, f_beta) + idn)   -- written once, it is the next identity
+ *           idn = identity, or batchnorm(identity; id_stats, id_gamma, id_beta) when id_stats is given (the previous block had a
+ *           downsample conv whose raw output is the identity; same count / eps as f_*)
+ *   y     = x_out (*) w_frag (1x1 fragment-major weights, layout code st_conv1x1_kfuse_supported(C, N)),  stats += [sum | sumsq] of y
+ * raw / identity / x_out: [rows][C] bf16 (x_out must not alias raw or identity), y: [rows][N] bf16.  Replaces one st_bn_act pass +
+ * the conv1 launch.  C = 256 / 512 (layer1 / layer2 and the first conv1 of layer2 / layer3): the register-resident-filter kernel's
+ * loader, same weights as st_conv1x1_wreg; C = 1024 -> N = 256: the K-streaming form (id_stats must be NULL). */
 typedef struct {
   const void* raw; const void* identity; void* x_out; const void* w_frag; void* y;
   float* stats; int stats_replicas;
   const float* f_stats; const float* f_gamma; const float* f_beta; float f_count; float f_eps; int f_stats_replicas;
   long rows; int C, N;
+  const float* id_stats; const float* id_gamma; const float* id_beta; int id_stats_replicas;
 } st_conv1x1_kfuse_desc;
+int st_conv1x1_kfuse_supported(int C, int N);
 int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream);
 /* The activation-stationary sibling for (C, N) = (256, 1024) / (512, 2048) (conv3 of the layer3 / layer4 Bottlenecks): a
  * workgroup keeps its 112 x C rows in LDS (producer's BatchNorm + ReLU applied once per element) and walks all N output

@@ -38,7 +38,8 @@ class Conv1x1WregDesc(C.Structure):
 class Conv1x1KfuseDesc(C.Structure):
     _fields_ = [("raw", c_p), ("identity", c_p), ("x_out", c_p), ("w_frag", c_p), ("y", c_p), ("stats", c_p), ("stats_replicas", c_i),
                 ("f_stats", c_p), ("f_gamma", c_p), ("f_beta", c_p), ("f_count", c_f), ("f_eps", c_f), ("f_stats_replicas", c_i),
-                ("rows", c_l), ("C", c_i), ("N", c_i)]
+                ("rows", c_l), ("C", c_i), ("N", c_i),
+                ("id_stats", c_p), ("id_gamma", c_p), ("id_beta", c_p), ("id_stats_replicas", c_i)]
 
 
 class BnActDesc(C.Structure):
@@ -95,6 +96,7 @@ _SIGS = {
     "st_conv1x1_wreg_supported": ([c_i, c_i], c_i),
     "st_conv1x1_wreg": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_conv1x1_kfuse": ([C.POINTER(Conv1x1KfuseDesc), c_p], c_i),
+    "st_conv1x1_kfuse_supported": ([c_i, c_i], c_i),
     "st_conv1x1_astat_supported": ([c_i, c_i], c_i),
     "st_conv1x1_astat": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_conv1x1_kstream_supported": ([c_i, c_i], c_i),

@@ -355,6 +355,10 @@ struct PwArgs {
   const float* in_stats; const float* in_gamma; const float* in_beta; float in_count, in_eps; int in_srep;
   int M, N, nbn, nstage, spb;            // rows, channels, channel slices, 16 TMS-row stages in all / per workgroup
   int Hin, Win, Ho, Wo, stride;          // stride > 1: output row (b, ho, wo) reads input pixel (b, ho * stride, wo * stride)
+  // FUSE (conv1 fused with the previous block's end): x is the RAW conv3 output, in_stats.. its BatchNorm; the loader forms
+  // relu(bn(x) + bn_r(res)) (bn_r = identity when res_stats is NULL), feeds it to the MFMAs and writes it ONCE to xout
+  const bf16_t* res; bf16_t* xout;
+  const float* res_stats; const float* res_gamma; const float* res_beta; int res_srep;
 };
 
 // relu(x * sc + sh) on 8 bf16 (one 16-byte chunk), rounded once: the same arithmetic as bn_act's pass
@@ -367,7 +371,7 @@ __device__ __forceinline__ void bn_relu_chunk(u32x4& v, const float* sc, const f
   }
 }
 
-template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE>
+template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE, bool FUSE = false>
 __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
   constexpr int PIX = 2 * K + 32;
   constexpr int KS = K / 32;
@@ -404,11 +408,13 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
   // ---- loader state ---------------------------------------------------------------------------------------------
   const int cch = tid % CH8, lrow = tid / CH8;
   const bool xf = a.in_stats != nullptr;
-  float sc[8], sh[8];
+  const bool rbn = FUSE && a.res_stats != nullptr;
+  float sc[8], sh[8], sc2[FUSE ? 8 : 1], sh2[FUSE ? 8 : 1];
   // D register sets: the rows of the next D stages are in flight while a stage is multiplied (a stage is shorter than one
   // HBM / L2 round trip: with one set every stage paid that round trip in full)
   u32x4 ra[D][NL]; bool rok[D][NL];
-  auto gload = [&](u32x4 (&r)[NL], bool (&ok)[NL], int stage) {
+  u32x4 rb[FUSE ? D : 1][FUSE ? NL : 1];           // FUSE: the residual rows travel with the raw ones
+  auto gload = [&](u32x4 (&r)[NL], bool (&ok)[NL], int stage, u32x4* q = nullptr) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       // UNCONDITIONAL loads (rows past the end re-read the last row; their results are never stored): a load under a branch
@@ -422,18 +428,35 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
         src = ((long)b * a.Hin + ho * a.stride) * a.Win + wo * a.stride;
       }
       r[i] = *reinterpret_cast<const u32x4*>(a.x + src * K + cch * 8);
+      if constexpr (FUSE) q[i] = *reinterpret_cast<const u32x4*>(a.res + src * K + cch * 8);
     }
   };
-  auto lstore = [&](u32x4 (&r)[NL], bool (&ok)[NL], int buf) {
+  auto lstore = [&](u32x4 (&r)[NL], bool (&ok)[NL], int buf, int stage = 0, const u32x4* q = nullptr) {
     char* base = smem + buf * STAGE_BYTES + lrow * PIX + cch * 16;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      if (xf) bn_relu_chunk(r[i], sc, sh);
-      *reinterpret_cast<u32x4*>(base + i * RPP * PIX) = r[i];
+      if constexpr (FUSE) {
+        // relu(bn(raw) + identity): st_bn_act's arithmetic (one fma per term, one rounding to bf16)
+        u32x4 v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          float rl = __uint_as_float(q[i][d] << 16), rh = __uint_as_float(q[i][d] & 0xffff0000u);
+          if (rbn) { rl = __builtin_fmaf(rl, sc2[2 * d], sh2[2 * d]); rh = __builtin_fmaf(rh, sc2[2 * d + 1], sh2[2 * d + 1]); }
+          const float lo = fmaxf(__builtin_fmaf(__uint_as_float(r[i][d] << 16), sc[2 * d], sh[2 * d]) + rl, 0.f);
+          const float hi = fmaxf(__builtin_fmaf(__uint_as_float(r[i][d] & 0xffff0000u), sc[2 * d + 1], sh[2 * d + 1]) + rh, 0.f);
+          v[d] = pack_bf16x2(lo, hi);
+        }
+        *reinterpret_cast<u32x4*>(base + i * RPP * PIX) = v;
+        // every channel slice forms the same rows; slice 0 writes them back (the next identity)
+        if (slice == 0 && ok[i]) *reinterpret_cast<u32x4*>(a.xout + (size_t)(stage * SM + lrow + i * RPP) * K + cch * 8) = v;
+      } else {
+        if (xf) bn_relu_chunk(r[i], sc, sh);
+        *reinterpret_cast<u32x4*>(base + i * RPP * PIX) = r[i];
+      }
     }
   };
 
-  gload(ra[0], rok[0], s_begin);
+  gload(ra[0], rok[0], s_begin, rb[0]);
   if (xf) {   // producer's BatchNorm coefficients (replicated statistics summed here), while the first rows are in flight
     float* coef = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
     const float inv = 1.0f / a.in_count;
@@ -444,15 +467,31 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
       const float var = fmaxf(sq * inv - mean * mean, 0.f);
       const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
       coef[c] = scv; coef[K + c] = a.in_beta[c] - mean * scv;
+      if constexpr (FUSE) {
+        float s2 = 1.f, h2 = 0.f;
+        if (rbn) {
+          float rm = 0.f, rq = 0.f;
+          for (int r = 0; r < a.res_srep; ++r) { rm += a.res_stats[(size_t)r * 2 * K + c]; rq += a.res_stats[(size_t)r * 2 * K + K + c]; }
+          const float m2 = rm * inv;
+          const float v2 = fmaxf(rq * inv - m2 * m2, 0.f);
+          s2 = a.res_gamma[c] * rsqrtf(v2 + a.in_eps);
+          h2 = a.res_beta[c] - m2 * s2;
+        }
+        coef[2 * K + c] = s2; coef[3 * K + c] = h2;
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = coef[cch * 8 + e]; sh[e] = coef[K + cch * 8 + e]; }
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc2[e] = coef[2 * K + cch * 8 + e]; sh2[e] = coef[3 * K + cch * 8 + e]; }
+    }
   }
-  lstore(ra[0], rok[0], 0);
+  lstore(ra[0], rok[0], 0, s_begin, rb[0]);
 #pragma unroll
   for (int j = 1; j <= D; ++j)                       // stage s_begin + j waits in register set j % D (always issued: counted waits)
-    gload(ra[j % D], rok[j % D], s_begin + j);
+    gload(ra[j % D], rok[j % D], s_begin + j, rb[FUSE ? j % D : 0]);
   __syncthreads();
 
   constexpr int NC = 4 * NTW;
@@ -526,8 +565,8 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
       }
     }
     // next stage: its register set -> the other ring half, then that set requests stage s + 1 + D
-    lstore(ra[(u + 1) % D], rok[(u + 1) % D], buf ^ 1);
-    gload(ra[(u + 1) % D], rok[(u + 1) % D], s + 1 + D);
+    lstore(ra[(u + 1) % D], rok[(u + 1) % D], buf ^ 1, s + 1, rb[FUSE ? (u + 1) % D : 0]);
+    gload(ra[(u + 1) % D], rok[(u + 1) % D], s + 1 + D, rb[FUSE ? (u + 1) % D : 0]);
     __syncthreads();
     }
    }
@@ -746,6 +785,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sstat = reinterpret_cast<float*>(smem + BM * PIX);          // [2][CW NCH] statistics of every chunk
   float* coef = sstat + 2 * CW * NCH;                                // [2][K] producer's scale / shift
+  float* aff = coef + 2 * K;                                         // AFFINE: [scale(N) | shift(N)] of the eval-mode epilogue (a global load
+                                                                     // inside the walk would drain the filter prefetch: vmcnt is in-order)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -794,6 +835,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         m = m < a.M ? m : a.M - 1;
         v[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)m * K + cch * 8);
       }
+    }
+    if constexpr (AFFINE) {
+      for (int c = tid; c < CW * NCH; c += 256) { aff[c] = a.scale[c]; aff[CW * NCH + c] = a.shift[c]; }
     }
     if (a.in_stats) {
       const float inv = 1.0f / a.in_count;
@@ -845,7 +889,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int c = 0; c < NC; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
       if constexpr (AFFINE) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = v[c] * a.scale[cb + c] + a.shift[cb + c];
+        for (int c = 0; c < NC; c += 4) {
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(aff + cb + c), h4 = *reinterpret_cast<const f32x4*>(aff + CW * NCH + cb + c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[c + q] = v[c + q] * s4[q] + h4[q];
+        }
         if (a.relu) {
 #pragma unroll
           for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -1206,25 +1254,34 @@ inline bool pw_cfg(int K, int N, PwCfg* c) {
   return false;
 }
 
-template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE>
+template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE, bool FUSE = false>
 int launch_pw___(PwArgs& a, hipStream_t st, double flops, bool xf) {
   constexpr int SM = 16 * TMS, PIX = 2 * K + 32;
-  const int lds = 2 * SM * PIX + (xf ? 2 * K * (int)sizeof(float) : 0);
+  const int lds = 2 * SM * PIX + (xf ? (FUSE ? 4 : 2) * K * (int)sizeof(float) : 0);
   a.nbn = a.N / (64 * NTW);
   a.nstage = (a.M + SM - 1) / SM;
-  int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ < 1) occ = 1;
+  static int attr_set[64] = {};
+  static int occ_dev[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev] && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[dev] = 1;
+  }
+  // workgroups that are resident together (registers AND LDS: the fused loader's two register sets leave 2 per CU where the LDS
+  // alone would take 3 -- a grid sized for 3 ran as one full round plus a 36 % one); the row range is cut into that many pieces
+  if (!occ_dev[dev]) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE>), 256, 160 * 1024 / 3) != hipSuccess || nb < 1) nb = 1;
+    occ_dev[dev] = nb;
+  }
+  int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ > occ_dev[dev]) occ = occ_dev[dev]; if (occ < 1) occ = 1;
   int mbs = (256 * occ) / a.nbn; if (mbs < 1) mbs = 1; if (mbs > a.nstage) mbs = a.nstage;
   a.spb = ((a.nstage + mbs - 1) / mbs + D - 1) / D * D;      // a multiple of the prefetch depth (kernel: straight-line unrolled body)
   mbs = (a.nstage + a.spb - 1) / a.spb;
-  static int attr_set[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 64 && !attr_set[dev] && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[dev] = 1;
-  }
   StProfScope prof(K == 64 ? 12 : K == 128 ? 13 : K == 256 ? 14 : 15, flops, st);
-  hipLaunchKernelGGL((conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE>), dim3(mbs * a.nbn), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE>), dim3(mbs * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
@@ -1264,7 +1321,7 @@ extern "C" int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream) {
   ST_CHECK(!d->residual, "st_conv1x1_wreg: no residual input (a load in the epilogue would drain the row prefetch): use st_conv");
   ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f), "st_conv1x1_wreg: input transform needs gamma, beta, count");
   ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->in_stats_replicas >= 0 && d->in_stats_replicas <= 1024, "st_conv1x1_wreg: bad stats_replicas");
-  PwArgs a;
+  PwArgs a{};
   a.x = reinterpret_cast<const bf16_t*>(d->x); a.w = reinterpret_cast<const bf16_t*>(d->w_frag); a.y = reinterpret_cast<bf16_t*>(d->y);
   a.stats = d->stats; a.srep = d->stats_replicas; a.scale = d->scale; a.shift = d->shift; a.relu = d->relu;
   a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_count = d->in_count; a.in_eps = d->in_eps;
@@ -1314,7 +1371,7 @@ int launch_ks(KsArgs& a, hipStream_t st, double flops) {
 namespace {
 template <int K, int NCH, bool AFFINE, bool STRIDED>
 int launch_as__(AsArgs& a, hipStream_t st, double flops) {
-  constexpr int lds = 112 * (2 * K + 32) + 2 * 128 * NCH * 4 + 2 * K * 4;
+  constexpr int lds = 112 * (2 * K + 32) + 2 * 128 * NCH * 4 + 2 * K * 4 + (AFFINE ? 2 * 128 * NCH * 4 : 0);
   static_assert(lds <= 160 * 1024, "activation block does not fit");
   static int attr_set[64] = {};
   int dev = 0;
@@ -1367,12 +1424,45 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   return strided ? launch_as_<512, 8, true>(a, st, flops) : launch_as_<512, 16, false>(a, st, flops);
 }
 
-// conv1 (C -> 256, C = 1024) fused with the previous block's end; see st_conv1x1_kfuse_desc in the header
+// conv1 fused with the previous block's end; see st_conv1x1_kfuse_desc in the header.  C = 1024 -> 256: the K-streaming form;
+// C = 256 / 512: the register-resident-filter kernel with the fused loader (layer1 / layer2, where the pass it removes is HBM time).
+namespace {
+int kfuse_wreg(const st_conv1x1_kfuse_desc* d, void* stream) {
+  PwCfg c;
+  ST_CHECK(pw_cfg(d->C, d->N, &c), "st_conv1x1_kfuse: unsupported geometry C=%d N=%d", d->C, d->N);
+  PwArgs a{};
+  a.x = reinterpret_cast<const bf16_t*>(d->raw); a.res = reinterpret_cast<const bf16_t*>(d->identity); a.xout = reinterpret_cast<bf16_t*>(d->x_out);
+  a.w = reinterpret_cast<const bf16_t*>(d->w_frag); a.y = reinterpret_cast<bf16_t*>(d->y);
+  a.stats = d->stats; a.srep = d->stats_replicas;
+  a.in_stats = d->f_stats; a.in_gamma = d->f_gamma; a.in_beta = d->f_beta; a.in_count = d->f_count; a.in_eps = d->f_eps;
+  a.in_srep = d->f_stats_replicas > 1 ? d->f_stats_replicas : 1;
+  a.res_stats = d->id_stats; a.res_gamma = d->id_gamma; a.res_beta = d->id_beta; a.res_srep = d->id_stats_replicas > 1 ? d->id_stats_replicas : 1;
+  a.M = (int)d->rows; a.N = d->N; a.stride = 1; a.Hin = 1; a.Win = a.M; a.Ho = 1; a.Wo = a.M;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const double flops = 2.0 * (double)d->rows * d->N * d->C;
+#define KF_CASE(KK, NT, TS, DD) if (d->C == KK && c.ntw == NT && c.tms == TS) return launch_pw___<KK, NT, TS, DD, false, false, true>(a, st, flops, true)
+  KF_CASE(256, 1, 2, 3); KF_CASE(256, 2, 4, 2); KF_CASE(512, 1, 2, 2);
+#undef KF_CASE
+  st_set_error("st_conv1x1_kfuse: no fused kernel for C=%d N=%d", d->C, d->N);
+  return 1;
+}
+}  // namespace
+
+extern "C" int st_conv1x1_kfuse_supported(int C, int N) {
+  if (C == 1024 && N == 256) return 4;
+  PwCfg c;
+  if ((C == 256 || C == 512) && pw_cfg(C, N, &c) && ((C == 256 && ((c.ntw == 1 && c.tms == 2) || (c.ntw == 2 && c.tms == 4))) || (C == 512 && c.ntw == 1 && c.tms == 2))) return c.ntw;
+  return 0;
+}
+
 extern "C" int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream) {
   ST_CHECK(d && d->raw && d->identity && d->x_out && d->w_frag && d->y && d->f_stats && d->f_gamma && d->f_beta, "st_conv1x1_kfuse: null pointer");
-  ST_CHECK(d->C == 1024 && d->N == 256, "st_conv1x1_kfuse: C=%d N=%d (1024 -> 256 only)", d->C, d->N);
-  ST_CHECK(d->rows > 0 && d->f_count > 0.f && d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->f_stats_replicas >= 0 && d->f_stats_replicas <= 1024,
+  ST_CHECK(d->rows > 0 && d->rows < (1L << 31) - 4096 && d->f_count > 0.f && d->f_stats_replicas >= 0 && d->f_stats_replicas <= 1024 && d->stats_replicas >= 0 && d->stats_replicas <= 1024,
            "st_conv1x1_kfuse: bad rows / count / replicas");
+  ST_CHECK(!d->id_stats || (d->id_gamma && d->id_beta && d->id_stats_replicas >= 0 && d->id_stats_replicas <= 1024), "st_conv1x1_kfuse: id_stats comes with id_gamma, id_beta");
+  if (d->C == 256 || d->C == 512) return kfuse_wreg(d, stream);
+  ST_CHECK(!d->id_stats, "st_conv1x1_kfuse: the 1024-channel form takes a normalised identity");
+  ST_CHECK(d->C == 1024 && d->N == 256, "st_conv1x1_kfuse: unsupported geometry C=%d N=%d", d->C, d->N);
   KfArgs a;
   a.raw = reinterpret_cast<const bf16_t*>(d->raw); a.res = reinterpret_cast<const bf16_t*>(d->identity); a.xout = reinterpret_cast<bf16_t*>(d->x_out);
   a.w = reinterpret_cast<const bf16_t*>(d->w_frag); a.y = reinterpret_cast<bf16_t*>(d->y);

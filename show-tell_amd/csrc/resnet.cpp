@@ -286,8 +286,11 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   // in_ci >= 0 (train): x is the RAW output of conv in_ci; this conv reads relu(bn_{in_ci}(x)) in its loader
   // keep_rep: the consumer of this layer's statistics sums the replicas itself (everything but st_conv's input transform and
   // the stem's pool): no reduction launch
+  // fz (train): x is the RAW conv3 output of the previous block (conv fz->ci); the loader forms relu(bn(x) + identity) itself, writes
+  // it to fz->xout (this block's input / identity) and the previous block's separate normalise pass does not run (st_conv1x1_kfuse)
+  struct FuseIn { int ci; const void* res; int res_ci; void* xout; };
   auto conv = [&](int ci, const void* x, int hin, int win, void* y, const void* eval_res, int eval_relu,
-                  int* ho, int* wo, int in_ci = -1, bool keep_rep = true) -> int {
+                  int* ho, int* wo, int in_ci = -1, bool keep_rep = true, const FuseIn* fz = nullptr) -> int {
     const ConvL& c = r->convs[ci];
     st_conv_desc d;
     memset(&d, 0, sizeof(d));
@@ -338,7 +341,22 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
       }
-      if (use_astat(c)) {
+      if (fz) {
+        const ConvL& pc = r->convs[fz->ci];
+        st_conv1x1_kfuse_desc k;
+        memset(&k, 0, sizeof(k));
+        k.raw = x; k.identity = fz->res; k.x_out = fz->xout; k.w_frag = g.w_frag; k.y = y;
+        k.stats = g.stats; k.stats_replicas = g.stats_replicas;
+        k.f_stats = stats + tab.soff[fz->ci]; k.f_gamma = bn_gamma + pc.bnoff; k.f_beta = bn_beta + pc.bnoff;
+        k.f_count = tab.count[fz->ci]; k.f_eps = eps; k.f_stats_replicas = tab.rep[fz->ci];
+        k.rows = (long)B * hin * win; k.C = c.cin; k.N = c.cout;
+        if (fz->res_ci >= 0) {
+          const ConvL& rc = r->convs[fz->res_ci];
+          k.id_stats = stats + tab.soff[fz->res_ci]; k.id_gamma = bn_gamma + rc.bnoff; k.id_beta = bn_beta + rc.bnoff;
+          k.id_stats_replicas = tab.rep[fz->res_ci];
+        }
+        if (st_conv1x1_kfuse(&k, stream)) return 1;
+      } else if (use_astat(c)) {
         if (st_conv1x1_astat(&g, stream)) return 1;
       } else if (c.cin > 512) {
         ST_CHECK(!g.in_stats, "st_resnet_forward: the long-K pointwise kernel has no input transform");
@@ -398,17 +416,33 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
   int cur = 0;  // wide[cur] holds the block input
 
-  for (const BlockL& b : r->blocks) {
+  // Train, 256-channel block inputs (layer1 and the first block of layer2): the block-end pass relu(bn3(raw) + identity) is formed by
+  // the NEXT block's conv1 loader (st_conv1x1_kfuse) -- that pass and conv1 are both HBM time there and the fusion drops one full read
+  // of the widest tensor (measured 168 -> 125 us per transition at 56 x 56, B = 128).  Wider inputs stay separate: their conv1 needs
+  // several channel slices per row (each would re-read both inputs) or, at 1024 channels, is MFMA-bound (measured slower fused).
+  static const bool kfuse_env = [] { const char* e = getenv("ST_BLOCK_FUSE"); return !e || atoi(e) != 0; }();
+  struct Pending { bool on; int ci; const void* res; int res_ci; int raw_buf, res_buf; } pend{false, -1, nullptr, -1, 0, 0};
+  for (size_t bi = 0; bi < r->blocks.size(); ++bi) {
+    const BlockL& b = r->blocks[bi];
+    FuseIn fzv; const FuseIn* fz = nullptr;
+    if (pend.on) {   // wide[cur] holds the previous block's RAW conv3 output; the buffer that is neither it nor the identity takes x
+      const int freeb = 3 - pend.raw_buf - pend.res_buf;
+      fzv = FuseIn{pend.ci, pend.res, pend.res_ci, wide[freeb]};
+      fz = &fzv;
+      cur = freeb;
+    }
     const int oth = (cur + 1) % 3, dsb = (cur + 2) % 3;
     int h1, w1, h2, w2, h3, w3, hd, wd;
     const void* xin = wide[cur];
+    const void* c1_in = fz ? static_cast<const void*>(wide[pend.raw_buf]) : xin;
+    pend.on = false;
     if (r->bottleneck) {
       // train: bn1 + relu ride in conv2's fill when the image-resident kernel takes conv2 (one pass over the tensor less)
       const ConvL& c2 = r->convs[b.c2];
       const ConvL& c3 = r->convs[b.c3];
       const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h, w, c2.cin, c2.cout) == c2.ntw;   // conv1 keeps the map size
       const bool c3_sums = train && use_img && c3.ntw > 0;       // conv3 on st_conv1x1_wreg: sums conv2's replicated statistics itself
-      if (conv(b.c1, xin, h, w, narrow[0], nullptr, 1, &h1, &w1)) return 1;
+      if (conv(b.c1, c1_in, h, w, narrow[0], nullptr, 1, &h1, &w1, -1, true, fz)) return 1;
       if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       const bool fuse2_ = train && c3.cin % 64 == 0;              // conv3 applies bn2 + relu in its loader
       if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, fuse1 ? b.c1 : -1, c3_sums || !fuse2_)) return 1;
@@ -422,7 +456,15 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         res = wide[dsb];
       }
       if (conv(b.c3, narrow[1], h2, w2, wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
-      if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
+      bool defer = false;
+      if (train && use_img && kfuse_env && bi + 1 < r->blocks.size()) {
+        const BlockL& nb = r->blocks[bi + 1];
+        const ConvL& n1 = r->convs[nb.c1];
+        defer = n1.k == 1 && n1.stride == 1 && n1.cin == 256 && n1.ntw > 0 && !use_astat(n1) && c3.cout == n1.cin &&
+                st_conv1x1_kfuse_supported(n1.cin, n1.cout) == n1.ntw;
+      }
+      if (defer) pend = Pending{true, b.c3, res, b.ds, oth, b.ds >= 0 ? dsb : cur};
+      else if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
     } else {
       const ConvL& c1 = r->convs[b.c1];
       const ConvL& c2 = r->convs[b.c2];

@@ -263,17 +263,26 @@ def conv1x1_wreg(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=Non
     return out
 
 
-def conv1x1_kfuse(raw, identity, w_frag, bn, stats=None, stats_replicas=0, x_out=None, out=None):
-    """st_conv1x1_kfuse: x = relu(bn(raw) + identity) (written to x_out), y = conv1x1(x) (1024 -> 256).  bn = dict(stats, gamma, beta,
-    count[, eps, replicas]).  Returns (x_out, y)."""
+def conv1x1_kfuse_supported(Cin, N):
+    return int(lib().st_conv1x1_kfuse_supported(Cin, N))
+
+
+def conv1x1_kfuse(raw, identity, w_frag, bn, N=256, id_bn=None, stats=None, stats_replicas=0, x_out=None, out=None):
+    """st_conv1x1_kfuse: x = relu(bn(raw) + identity) (written to x_out; identity normalised with id_bn first when given),
+    y = conv1x1(x) (C -> N).  bn / id_bn = dict(stats, gamma, beta[, count, eps, replicas]).  Returns (x_out, y)."""
     _dev(raw, identity, w_frag, stats, x_out, out, bn["stats"], bn["gamma"], bn["beta"])
     rows = raw.numel() // raw.shape[-1]
     if x_out is None:
         x_out = torch.empty_like(raw)
     if out is None:
-        out = torch.empty(*raw.shape[:-1], 256, device=raw.device, dtype=torch.bfloat16)
+        out = torch.empty(*raw.shape[:-1], N, device=raw.device, dtype=torch.bfloat16)
     d = Conv1x1KfuseDesc(_p(raw), _p(identity), _p(x_out), _p(w_frag), _p(out), _p(stats), int(stats_replicas), _p(bn["stats"]), _p(bn["gamma"]),
-                         _p(bn["beta"]), float(bn["count"]), float(bn.get("eps", 1e-5)), int(bn.get("replicas", 0)), rows, raw.shape[-1], 256)
+                         _p(bn["beta"]), float(bn["count"]), float(bn.get("eps", 1e-5)), int(bn.get("replicas", 0)), rows, raw.shape[-1], N,
+                         None, None, None, 0)
+    if id_bn is not None:
+        _dev(id_bn["stats"], id_bn["gamma"], id_bn["beta"])
+        d.id_stats, d.id_gamma, d.id_beta = id_bn["stats"].data_ptr(), id_bn["gamma"].data_ptr(), id_bn["beta"].data_ptr()
+        d.id_stats_replicas = int(id_bn.get("replicas", 0))
     check(lib().st_conv1x1_kfuse(C.byref(d), _stream()), "st_conv1x1_kfuse")
     return x_out, out
 

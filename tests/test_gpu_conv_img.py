@@ -307,3 +307,51 @@ def test_conv1x1_kfuse_equals_bn_act_then_kstream(rows_shape):
     np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s0.cpu().numpy(), rtol=1e-4, atol=1e-2)
     ref = F.conv2d(x_ref.float().cpu().permute(0, 3, 1, 2), w, None, 1, 0).permute(0, 2, 3, 1)
     assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+
+
+# (rows shape, C, N, identity needs its own BatchNorm): the fused loader of the register-resident-filter kernel (layer1 / layer2 widths)
+KF_PW_CASES = [((2, 56, 56), 256, 64, False), ((3, 28, 28), 256, 128, False), ((2, 28, 28), 512, 128, False), ((2, 28, 28), 512, 256, False),
+               ((1, 56, 56), 256, 64, True), ((3, 9, 7), 512, 128, True), ((1, 1, 5), 256, 128, False)]
+
+
+@pytest.mark.parametrize("case", KF_PW_CASES)
+def test_conv1x1_kfuse_register_filter_form_equals_bn_act_then_wreg(case):
+    """C = 256 / 512: x_out == st_bn_act(raw, res = identity[, res_bn]) bit for bit, y == st_conv1x1_wreg on that x bit for bit, for
+    every channel-slice count (N = 64 .. 256: 1 - 4 slices read the same rows, slice 0 writes x_out)."""
+    ops = _ops()
+    shape, C, N, idbn = case
+    B, H, W = shape
+    ntw = ops.conv1x1_kfuse_supported(C, N)
+    assert ntw > 0 and ntw == ops.conv1x1_wreg_supported(C, N)
+    g = torch.Generator().manual_seed(B * H + W + C + N)
+    raw = (torch.randn(B, H, W, C, generator=g) * 1.3 + 0.1).bfloat16().cuda()
+    ident = (torch.randn(B, H, W, C, generator=g) * (1.0 if idbn else 0.7)).bfloat16().cuda()
+    if not idbn:
+        ident = torch.relu(ident)
+    w = (torch.randn(N, C, 1, 1, generator=g) / np.sqrt(C)).bfloat16().float()
+    wf = ops.pack_conv_weight_frag(w.cuda(), ntw)
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    gam2, bet2 = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    n = float(B * H * W)
+
+    def stats_of(t):
+        t2 = t.float().reshape(-1, C)
+        return torch.cat([t2.sum(0), (t2 * t2).sum(0)]).contiguous()
+    st_raw, st_id = stats_of(raw), stats_of(ident)
+    rep = torch.zeros(4, 2 * C, device="cuda"); rep[2] = st_raw
+    rep_id = torch.zeros(2, 2 * C, device="cuda"); rep_id[1] = st_id
+    kw = dict(res=ident)
+    if idbn:
+        kw.update(res_bn=dict(stats=st_id, gamma=gam2, beta=bet2))
+    x_ref = ops.bn_act(raw, gam, bet, stats=st_raw, count=n, relu=True, **kw)
+    s0 = torch.zeros(2 * N, device="cuda")
+    y_ref = ops.conv1x1_wreg(x_ref, wf, N, stats=s0)
+    s1 = torch.zeros(2, 2 * N, device="cuda")
+    x, y = ops.conv1x1_kfuse(raw, ident, wf, dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=4), N=N,
+                             id_bn=dict(stats=rep_id, gamma=gam2, beta=bet2, replicas=2) if idbn else None, stats=s1, stats_replicas=2)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x_ref)
+    assert torch.equal(y, y_ref)
+    np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s0.cpu().numpy(), rtol=2e-3, atol=2e-2 * np.sqrt(n))
+    ref = F.conv2d(x_ref.float().cpu().permute(0, 3, 1, 2), w, None, 1, 0).permute(0, 2, 3, 1)
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
