@@ -212,6 +212,23 @@ int st_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int 
 int st_maxpool3x3s2_bn(const void* x, void* y, int dtype, int B, int H, int W, int C,
                        const float* stats, const float* gamma, const float* beta,
                        const float* running_mean, const float* running_var, float count, float eps, void* stream);
+/* The bf16 stem in one kernel (csrc/conv_stem.hip): conv1 7x7/2 (+ BatchNorm statistics) + maxpool 3x3/2 of torchvision's resnet
+ * (the first four modules of the reference's `self.model`, cnn.py:46); replaces st_conv on the blocked image + st_maxpool3x3s2(_bn).
+ *   x_s2d : st_nchw_to_s2d16's blocked image [B][H/2+3][W/2+3][16] bf16;  w_frag : st_stem_weight_frag(st_stem_weight_s2d(..)) (64 x 256)
+ *   y     : [B][PH][PW][64] bf16, PH = (H/2 - 1)/2 + 1
+ * train (scale == NULL): y = pool(raw conv output) with MAX on channels with gamma >= 0 and MIN on the others -- the consumer applies
+ *   relu(bn1(.)) to y (monotone per channel, so this IS maxpool(relu(bn1(conv)))); stats[replica][sum(64) | sumsq(64)] += the raw
+ *   convolution output's sums over all B x H/2 x W/2 positions (fp32 accumulators), replica = workgroup %% stats_replicas.
+ * eval (scale, shift = folded bn1): y = maxpool(relu(conv * scale + shift)). */
+typedef struct {
+  const void* x_s2d; const void* w_frag; void* y;
+  float* stats; int stats_replicas;
+  const float* gamma;
+  const float* scale; const float* shift;
+  int B, H, W;
+} st_stem_conv_pool_desc;
+int st_stem_conv_pool(const st_stem_conv_pool_desc* d, void* stream);
+int st_stem_weight_frag(const void* w_s2d, void* out, void* stream);
 /* global average pool NHWC -> [B][C] (adaptive avgpool, cnn.py:34) */
 int st_global_avgpool(const void* x, void* y, int dtype, int out_dtype, int B, int HW, int C, void* stream);
 

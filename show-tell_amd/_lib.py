@@ -42,6 +42,11 @@ class Conv1x1KfuseDesc(C.Structure):
                 ("id_stats", c_p), ("id_gamma", c_p), ("id_beta", c_p), ("id_stats_replicas", c_i)]
 
 
+class StemConvPoolDesc(C.Structure):
+    _fields_ = [("x_s2d", c_p), ("w_frag", c_p), ("y", c_p), ("stats", c_p), ("stats_replicas", c_i), ("gamma", c_p),
+                ("scale", c_p), ("shift", c_p), ("B", c_i), ("H", c_i), ("W", c_i)]
+
+
 class BnActDesc(C.Structure):
     _fields_ = [("x", c_p), ("y", c_p), ("res", c_p), ("stats", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("res_stats", c_p), ("res_gamma", c_p),
@@ -111,6 +116,8 @@ _SIGS = {
     "st_nchw_to_nhwc": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_nchw_to_s2d16": ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_stem_weight_s2d": ([c_p, c_p, c_i, c_i, c_p], c_i),
+    "st_stem_weight_frag": ([c_p, c_p, c_p], c_i),
+    "st_stem_conv_pool": ([C.POINTER(StemConvPoolDesc), c_p], c_i),
     "st_nhwc_to_ncp_f32": ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_maxpool3x3s2": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_maxpool3x3s2_bn": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p], c_i),

@@ -407,13 +407,42 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   };
 
   int h, w;
-  if (conv(0, in8, H, W, stem, nullptr, 1, &h, &w, -1, false)) return 1;
-  if (train) {   // bn1 + relu folded into the pool: the 64-channel 112x112 map is read once instead of three times
+  // bf16 bottleneck nets on even image sizes: the whole stem (conv1 + statistics + maxpool) is ONE kernel (conv_stem.hip).  In train
+  // mode it leaves the pooled RAW conv output in wide[0]; bn1 + relu are applied by the loaders of its two consumers (conv1 and the
+  // downsample conv of the first block) -- pooling commutes with the monotone per-channel map, see conv_stem.hip.
+  static const bool stem_env = [] { const char* e = getenv("ST_STEM_FUSE"); return !e || atoi(e) != 0; }();
+  bool stem_fused = stem_env && s2d && use_img && r->bottleneck && !r->blocks.empty();
+  if (stem_fused) {
+    const BlockL& b0 = r->blocks[0];
+    stem_fused = b0.ds >= 0 && r->convs[b0.c1].k == 1 && r->convs[b0.c1].stride == 1 && r->convs[b0.c1].ntw > 0 && r->convs[b0.ds].ntw > 0 &&
+                 r->convs[b0.c1].cin == 64 && !use_astat(r->convs[b0.ds]);
+  }
+  if (stem_fused) {
     const ConvL& c0 = r->convs[0];
-    if (st_maxpool3x3s2_bn(stem, wide[0], dt, B, h, w, 64, stats + tab.soff[0], bn_gamma + c0.bnoff, bn_beta + c0.bnoff,
-                           nullptr, nullptr, (float)((long)B * h * w), eps, stream)) return 1;
-  } else if (st_maxpool3x3s2(stem, wide[0], dt, B, h, w, 64, stream)) return 1;
+    char* wfrag = stem;                                 // the 205-MB raw-output buffer is free in this form: 32 KB of it hold the filters
+    if (st_stem_weight_frag(s2dw, wfrag, stream)) return 1;
+    st_stem_conv_pool_desc sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.x_s2d = in8; sd.w_frag = wfrag; sd.y = wide[0]; sd.B = B; sd.H = H; sd.W = W;
+    h = conv_out(H, 7, 2, 3); w = conv_out(W, 7, 2, 3);
+    tab.count[0] = (float)((long)B * h * w);
+    if (train) {
+      tab.soff[0] = stats_used; tab.rep[0] = 8; stats_used += 8 * 2 * c0.cout;
+      sd.stats = stats + tab.soff[0]; sd.stats_replicas = 8; sd.gamma = bn_gamma + c0.bnoff;
+    } else {
+      sd.scale = fscale + c0.bnoff; sd.shift = fshift + c0.bnoff;
+    }
+    if (st_stem_conv_pool(&sd, stream)) return 1;
+  } else {
+    if (conv(0, in8, H, W, stem, nullptr, 1, &h, &w, -1, false)) return 1;
+    if (train) {   // bn1 + relu folded into the pool: the 64-channel 112x112 map is read once instead of three times
+      const ConvL& c0 = r->convs[0];
+      if (st_maxpool3x3s2_bn(stem, wide[0], dt, B, h, w, 64, stats + tab.soff[0], bn_gamma + c0.bnoff, bn_beta + c0.bnoff,
+                             nullptr, nullptr, (float)((long)B * h * w), eps, stream)) return 1;
+    } else if (st_maxpool3x3s2(stem, wide[0], dt, B, h, w, 64, stream)) return 1;
+  }
   h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
+  const int stem_in = (stem_fused && train) ? 0 : -1;   // the first block's conv1 / downsample read relu(bn1(.)) of wide[0] in their loaders
   int cur = 0;  // wide[cur] holds the block input
 
   // Train, 256-channel block inputs (layer1 and the first block of layer2): the block-end pass relu(bn3(raw) + identity) is formed by
@@ -442,7 +471,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       const ConvL& c3 = r->convs[b.c3];
       const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h, w, c2.cin, c2.cout) == c2.ntw;   // conv1 keeps the map size
       const bool c3_sums = train && use_img && c3.ntw > 0;       // conv3 on st_conv1x1_wreg: sums conv2's replicated statistics itself
-      if (conv(b.c1, c1_in, h, w, narrow[0], nullptr, 1, &h1, &w1, -1, true, fz)) return 1;
+      if (conv(b.c1, c1_in, h, w, narrow[0], nullptr, 1, &h1, &w1, bi == 0 ? stem_in : -1, true, fz)) return 1;
       if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       const bool fuse2_ = train && c3.cin % 64 == 0;              // conv3 applies bn2 + relu in its loader
       if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, fuse1 ? b.c1 : -1, c3_sums || !fuse2_)) return 1;
@@ -452,7 +481,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       if (train && !fuse2 && bnact(b.c2, narrow[1], (long)B * h2 * w2, 1, nullptr, -1)) return 1;
       const void* res = xin;
       if (b.ds >= 0) {
-        if (conv(b.ds, xin, h, w, wide[dsb], nullptr, 0, &hd, &wd)) return 1;
+        if (conv(b.ds, xin, h, w, wide[dsb], nullptr, 0, &hd, &wd, bi == 0 ? stem_in : -1)) return 1;
         res = wide[dsb];
       }
       if (conv(b.c3, narrow[1], h2, w2, wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;

@@ -8,7 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ST_BF16, ST_F32, BnActDesc, Conv1x1KfuseDesc, Conv1x1WregDesc, Conv3x3ImgDesc, ConvDesc, check, lib
+from ._lib import (ST_BF16, ST_F32, BnActDesc, Conv1x1KfuseDesc, Conv1x1WregDesc, Conv3x3ImgDesc, ConvDesc, StemConvPoolDesc,
+                   check, lib)
 
 _DT = {torch.float32: ST_F32, torch.bfloat16: ST_BF16}
 
@@ -78,6 +79,27 @@ def stem_conv_s2d(images, w_packed, cpad, dtype, stats=None, scale=None, shift=N
                  16, 256, 64, int(relu), 0, 36, 0, 0)
     check(lib().st_conv(C.byref(d), _stream()), "st_conv(s2d stem)")
     return out, xs, ws
+
+
+def stem_conv_pool(images, w_packed, cpad, stats=None, stats_replicas=0, gamma=None, scale=None, shift=None):
+    """The bf16 stem in one kernel (st_stem_conv_pool): conv 7x7/2 + statistics + maxpool 3x3/2.  images (B,3,H,W) fp32, even H, W;
+    w_packed the usual (64, 7*7*cpad) bf16 k_order-0 weights.  Train (gamma, stats): the pooled RAW output (max / min by sign(gamma));
+    eval (scale, shift): maxpool(relu(conv * scale + shift)).  Returns (B, PH, PW, 64) bf16."""
+    _dev(images, w_packed, stats, gamma, scale, shift)
+    B, Cc, H, W = images.shape
+    assert Cc == 3 and images.dtype == torch.float32
+    dt = torch.bfloat16
+    xs = torch.empty(B, H // 2 + 3, W // 2 + 3, 16, device=images.device, dtype=dt)
+    check(lib().st_nchw_to_s2d16(_p(images), _p(xs), _DT[dt], B, H, W, _stream()), "st_nchw_to_s2d16")
+    ws = torch.empty(64, 256, device=images.device, dtype=dt)
+    check(lib().st_stem_weight_s2d(_p(w_packed), _p(ws), _DT[dt], cpad, _stream()), "st_stem_weight_s2d")
+    wf = torch.empty(64 * 256, device=images.device, dtype=dt)
+    check(lib().st_stem_weight_frag(_p(ws), _p(wf), _stream()), "st_stem_weight_frag")
+    PH, PW = (H // 2 - 1) // 2 + 1, (W // 2 - 1) // 2 + 1
+    out = torch.empty(B, PH, PW, 64, device=images.device, dtype=dt)
+    d = StemConvPoolDesc(_p(xs), _p(wf), _p(out), _p(stats), int(stats_replicas), _p(gamma), _p(scale), _p(shift), B, H, W)
+    check(lib().st_stem_conv_pool(C.byref(d), _stream()), "st_stem_conv_pool")
+    return out
 
 
 def gemm_nt(a, w, out_dtype=None, bias=None, out=None, accumulate=False, stats=None, relu=False,

@@ -413,3 +413,48 @@ def test_bad_arguments_fail_loudly():
         ops.conv_nhwc(x, w, 1, 1, 1, 0)
     with pytest.raises(ShowTellHipError):
         ops.cast(torch.zeros(4), torch.bfloat16)                        # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 32, 48), (1, 224, 224), (2, 34, 70), (1, 8, 8)])
+def test_stem_conv_pool_one_kernel_matches_conv_bn_relu_maxpool(B, H, W):
+    """st_stem_conv_pool (conv1 7x7/2 + statistics + 3x3/2 pool in one kernel) against torch's conv2d -> BatchNorm (batch statistics)
+    -> ReLU -> MaxPool2d(3, 2, 1) (torchvision resnet's first four modules, cnn.py:46), and BIT FOR BIT against the two-kernel form
+    (st_conv on the blocked image, st_maxpool3x3s2_bn).  Train mode pools the RAW output with max where gamma >= 0 and min where
+    gamma < 0 and leaves bn1 + relu to the consumer: both signs are in gamma here."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3 * H + W)
+    x = torch.randn(B, 3, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(64, 3, 7, 7, generator=g) / np.sqrt(147)).bfloat16().float()
+    gamma = torch.rand(64, generator=g) + 0.5
+    gamma[::3] *= -1.0                                   # a third of the channels pool with MIN
+    beta = torch.randn(64, generator=g) * 0.3
+    wpad = torch.zeros(64, 8, 7, 7); wpad[:, :3] = w
+    wd = ops.pack_conv_weight(wpad.cuda(), torch.bfloat16)
+    xd = x.cuda()
+    # two-kernel form
+    s0 = torch.zeros(128, device="cuda")
+    raw, _, _ = ops.stem_conv_s2d(xd, wd, 8, torch.bfloat16, stats=s0)
+    n = float(B * (H // 2) * (W // 2))
+    two = ops.maxpool3x3s2_bn(raw, gamma.cuda(), beta.cuda(), stats=s0, count=n)
+    # one kernel: pooled raw values + replicated statistics, then bn1 + relu as a consumer would apply them
+    R = 4
+    s1 = torch.zeros(R, 128, device="cuda")
+    pooled = ops.stem_conv_pool(xd, wd, 8, stats=s1, stats_replicas=R, gamma=gamma.cuda())
+    torch.cuda.synchronize()
+    tot = s1.sum(0)
+    np.testing.assert_allclose(tot.cpu().numpy(), s0.cpu().numpy(), rtol=2e-4, atol=2e-3 * np.sqrt(n))
+    one = ops.bn_act(pooled, gamma.cuda(), beta.cuda(), stats=s0, count=n, relu=True)     # same statistics as `two`: bit-exact check
+    assert one.shape == two.shape
+    assert torch.equal(one, two)
+    # against torch fp32
+    conv = F.conv2d(x, w, None, 2, 3)
+    ref = F.max_pool2d(F.relu(F.batch_norm(conv, None, None, gamma, beta, True, 0.0, 1e-5)), 3, 2, 1).permute(0, 2, 3, 1)
+    assert (one.float().cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+    # eval: folded scale / shift
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    sc[1::4] *= -1.0
+    y_e = ops.stem_conv_pool(xd, wd, 8, scale=sc.cuda(), shift=sh.cuda())
+    raw_e, _, _ = ops.stem_conv_s2d(xd, wd, 8, torch.bfloat16, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    assert torch.equal(y_e, ops.maxpool3x3s2(raw_e))
+    ref_e = F.max_pool2d(F.relu(conv * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1).permute(0, 2, 3, 1)
+    assert (y_e.float().cpu() - ref_e).abs().max().item() <= 3e-2 * ref_e.abs().max().item()
