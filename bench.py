@@ -271,6 +271,8 @@ def main():
         for i_, c_ in enumerate((256, 512)):
             names[18 + i_] = "conv1x1_astat_kernel<%d,...> (pointwise, activation-stationary, csrc/conv_img.hip)" % c_
             prefixes[18 + i_] = ("conv1x1_astat_kernel<%d," % c_,)
+        names[20] = "stem_pool_kernel (conv 7x7/2 + statistics + 3x3/2 pool in one kernel, csrc/conv_stem.hip)"
+        prefixes[20] = ("stem_pool_kernel<",)
         v = max(range(32), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12 if ms[v] > 0 else 0.0
         tot_ms, tot_fl = sum(ms), sum(fl)

@@ -17,7 +17,7 @@ def short(name):
     if m:
         return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
     for k in ("igemm_s3b_kernel", "igemm_s3_kernel", "bn_act_reg_kernel", "bn_act_kernel", "vocab_argmax_lds_kernel", "maxpool_kernel",
-              "transpose_kernel", "ce_kernel", "sgd_kernel", "nchw_to_s2d_kernel", "bn_reduce_replicas_kernel"):
+              "transpose_kernel", "ce_kernel", "sgd_kernel", "nchw_to_s2d_kernel", "bn_reduce_replicas_kernel", "stem_pool_kernel"):
         if k in name:
             return k
     m = re.search(r"rnn_gemm_kernel.*", name)
