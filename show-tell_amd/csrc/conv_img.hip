@@ -765,7 +765,7 @@ struct AsArgs {
   float* stats; int srep;
   const float* scale; const float* shift; int relu;
   const float* in_stats; const float* in_gamma; const float* in_beta; float in_count, in_eps; int in_srep;
-  int M, N;
+  int M, N, nq;                  // nq: channel parts (workgroups per row block)
   int Hin, Win, Ho, Wo, stride;  // STRIDED: output row (b, ho, wo) reads input pixel (b, ho * stride, wo * stride)
   unsigned long long* stamps;   // debug (tools/as_stamps.py), normally NULL
 };
@@ -790,15 +790,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bm;
+  // a.nq > 1: the output channels are cut into nq parts of NCH chunks each, one workgroup per (row block, part) -- layers with few rows
+  // (512 -> 2048 at 7 x 7: 56 row blocks) fill the chip that way; the parts of a row block are neighbours on one XCD (its rows: L2 hits)
+  int bm, bq;
   {
     const int nblk = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
-    bm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    bm = lid / a.nq; bq = lid - bm * a.nq;
   }
+  const int ch0 = bq * NCH;                                          // first 128-channel chunk of this workgroup
   const int r16 = lane & 15, q4 = lane >> 4;
   const u32x4* wl = reinterpret_cast<const u32x4*>(a.w) + lane;
   // K-step g of the walk: chunk g / KS, k-step g % KS, this wave's tiles (chunk * 4 + wid) * NTW + j
-  auto wfrag = [&](int g, int j) { return wl[((size_t)(((g / KS) * 4 + wid) * NTW + j) * KS + g % KS) * 64]; };
+  auto wfrag = [&](int g, int j) { return wl[((size_t)(((ch0 + g / KS) * 4 + wid) * NTW + j) * KS + g % KS) * 64]; };
 #define AS_STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   AS_STAMP(0);
   if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -837,7 +841,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     if constexpr (AFFINE) {
-      for (int c = tid; c < CW * NCH; c += 256) { aff[c] = a.scale[c]; aff[CW * NCH + c] = a.shift[c]; }
+      for (int c = tid; c < CW * NCH; c += 256) { aff[c] = a.scale[ch0 * CW + c]; aff[CW * NCH + c] = a.shift[ch0 * CW + c]; }
     }
     if (a.in_stats) {
       const float inv = 1.0f / a.in_count;
@@ -873,7 +877,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float es[NC], ess[NC];
   // tile i of chunk `ch` from accumulator set `acc`: statistics partials, (eval: scale / shift / ReLU), bf16, one 16-byte store
   auto tile_epilogue = [&](f32x4 (&acc)[TM][NTW], int ch, int i) {
-    const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;             // this lane's 8 consecutive channels
+    const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;             // this lane's 8 consecutive channels (inside the workgroup's part)
     const int m = bm * BM + i * 16 + r16;
     if (i == 0) {
 #pragma unroll
@@ -899,7 +903,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
         }
       }
-      *reinterpret_cast<u32x4*>(a.y + (size_t)m * a.N + cb) =
+      *reinterpret_cast<u32x4*>(a.y + (size_t)m * a.N + ch0 * CW + cb) =
           u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
     }
   };
@@ -958,7 +962,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (a.stats) {
     float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);
     __syncthreads();
-    for (int t = tid; t < 2 * CW * NCH; t += 256) atomicAdd(sdst + t, sstat[t]);   // [sum(N) | sumsq(N)] is exactly sstat's layout (N = CW NCH)
+    for (int t = tid; t < 2 * CW * NCH; t += 256)                  // sstat = [sum | sumsq] of this part's CW NCH channels
+      atomicAdd(sdst + (t < CW * NCH ? ch0 * CW + t : a.N + ch0 * CW + t - CW * NCH), sstat[t]);
   }
   AS_STAMP(5);
   if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
@@ -1381,7 +1386,7 @@ int launch_as__(AsArgs& a, hipStream_t st, double flops) {
     attr_set[dev] = 1;
   }
   StProfScope prof(K == 256 ? 18 : 19, flops, st);
-  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED>), dim3((a.M + 111) / 112), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED>), dim3(((a.M + 111) / 112) * a.nq), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
@@ -1420,8 +1425,12 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   a.M = (int)M; a.N = d->N; a.stamps = st_debug_stamps_ptr();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)M * d->N * d->C;
+  a.nq = 1;
   if (d->C == 256) return strided ? launch_as_<256, 4, true>(a, st, flops) : launch_as_<256, 8, false>(a, st, flops);
-  return strided ? launch_as_<512, 8, true>(a, st, flops) : launch_as_<512, 16, false>(a, st, flops);
+  if (strided) return launch_as_<512, 8, true>(a, st, flops);
+  // 512 -> 2048: with <= 128 row blocks the channels are cut in four parts (56 row blocks at 7 x 7, B = 128: 224 workgroups)
+  if ((a.M + 111) / 112 <= 128) { a.nq = 4; return launch_as_<512, 4, false>(a, st, flops); }
+  return launch_as_<512, 16, false>(a, st, flops);
 }
 
 // conv1 fused with the previous block's end; see st_conv1x1_kfuse_desc in the header.  C = 1024 -> 256: the K-streaming form;

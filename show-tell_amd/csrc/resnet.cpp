@@ -22,13 +22,14 @@
 
 struct ConvL { int cin, cout, k, stride, pad; size_t woff; size_t bnoff; int korder; size_t woff_frag; int ntw; };   // woff_frag: fragment-major copy for st_conv3x3_img (ntw > 0)
 struct BlockL { int c1, c2, c3, ds; int stride; };
-// The activation-stationary pointwise kernel (one workgroup per 112 rows) takes the 256 -> 1024 conv3 of layer3 and the stride-2
-// downsample convs of layer2 / layer3 (256 -> 512, 512 -> 1024: many output-channel slices per input row); layer4's 512 -> 2048
-// has only 49 rows per image (56 workgroups at B = 128: measured 63 us against 32 on st_conv1x1_wreg) and stays there.  Static per
-// layer: the fragment-major copy is packed for ONE kernel's channel permutation (ntw).
+// The activation-stationary pointwise kernel (one workgroup per 112 rows) takes the 256 -> 1024 conv3 of layer3, the stride-2
+// downsample convs of layer2 / layer3 (256 -> 512, 512 -> 1024: many output-channel slices per input row) and layer4's 512 -> 2048
+// (49 rows per image: 56 row blocks at B = 128, so the channels are cut into four parts per row block there -- as one workgroup
+// per row block it measured 63 us against 32 on st_conv1x1_wreg).  Static per layer: the fragment-major copy is packed for ONE
+// kernel's channel permutation (ntw).
 static inline bool use_astat(const ConvL& c) {
   if (c.k != 1) return false;
-  if (c.stride == 1) return c.cin == 256 && c.cout == 1024;
+  if (c.stride == 1) return (c.cin == 256 && c.cout == 1024) || (c.cin == 512 && c.cout == 2048);   // conv3 of layer3 / layer4
   return c.stride == 2 && ((c.cin == 256 && c.cout == 512) || (c.cin == 512 && c.cout == 1024));   // downsample convs of layer2 / layer3
 }
 

@@ -236,6 +236,7 @@ def test_conv1x1_kstream_matches_conv2d_and_igemm(case):
 
 # ---- st_conv1x1_astat: (B, H, W, C, N) -----------------------------------------------------------------------------------
 AS_CASES = [(4, 14, 14, 256, 1024, 1), (5, 7, 7, 512, 2048, 1), (1, 3, 5, 256, 1024, 1),
+            (74, 14, 14, 512, 2048, 1),   # > 128 row blocks: one workgroup per row block walks all 2048 channels (fewer: four channel parts)
             (3, 28, 28, 256, 512, 2), (2, 28, 28, 512, 1024, 2), (5, 9, 7, 256, 512, 2), (1, 1, 3, 512, 1024, 2)]   # stride 2: the downsample convs
 
 
