@@ -472,10 +472,14 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       const ConvL& c3 = r->convs[b.c3];
       const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h, w, c2.cin, c2.cout) == c2.ntw;   // conv1 keeps the map size
       const bool c3_sums = train && use_img && c3.ntw > 0;       // conv3 on st_conv1x1_wreg: sums conv2's replicated statistics itself
-      if (conv(b.c1, c1_in, h, w, narrow[0], nullptr, 1, &h1, &w1, bi == 0 ? stem_in : -1, true, fz)) return 1;
-      if (train && !fuse1 && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
+      // conv2 on st_conv (the three stride-2 3x3s): its loader takes bn1 + relu too (igemm MODE 2, padding taps stay zero); it reads
+      // replica 0 of conv1's statistics, so conv1's replicas are reduced by a launch (5 us against a 14 - 44 us pass over the tensor)
+      static const bool xf_env = [] { const char* e = getenv("ST_CONV2_XF"); return !e || atoi(e) != 0; }();
+      const bool fuse1x = xf_env && train && use_img && !fuse1 && c2.k == 3 && c2.cin % 64 == 0;
+      if (conv(b.c1, c1_in, h, w, narrow[0], nullptr, 1, &h1, &w1, bi == 0 ? stem_in : -1, !fuse1x, fz)) return 1;
+      if (train && !fuse1 && !fuse1x && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       const bool fuse2_ = train && c3.cin % 64 == 0;              // conv3 applies bn2 + relu in its loader
-      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, fuse1 ? b.c1 : -1, c3_sums || !fuse2_)) return 1;
+      if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, (fuse1 || fuse1x) ? b.c1 : -1, c3_sums || !fuse2_)) return 1;
       // train: bn2 + relu are applied by conv3's loader (no separate pass over the 3x3 output); needs whole 64-channel
       // (f32: 32) K tiles, which every bottleneck width satisfies
       const bool fuse2 = train && r->convs[b.c3].cin % 64 == 0;
