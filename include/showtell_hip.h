@@ -112,7 +112,7 @@ int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream);
  * x: [B][Hin][Win][C] bf16 (dense), y: [B][Ho][Wo][N] bf16 with Ho = (Hin - 1) / stride + 1;
  * w_frag: st_pack_conv_weight_frag(.., KH = KW = 1, ntw = st_conv1x1_wreg_supported(C, N)).
  * in_stats / stats / scale / shift / relu as in st_conv3x3_img_desc; residual must be NULL (reserved: an epilogue that adds a
- * residual stays with st_conv).
+ * residual stays with st_conv).  y may be NULL in train mode (stats given): only the statistics of the output are produced.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const void* x; const void* w_frag; void* y; const void* residual;
@@ -146,6 +146,24 @@ typedef struct {
 } st_conv1x1_kfuse_desc;
 int st_conv1x1_kfuse_supported(int C, int N);
 int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream);
+/* Block boundary of the 56 x 56 Bottlenecks in one pass over the wide tensors (csrc/conv_b2b.hip; train mode, bf16):
+ *   x_out = relu(bn3(conv3(relu(bn2(raw2)))) + idn),   y = conv1_next(x_out)   (+ statistics of y)
+ * conv3 (C1 = 64 -> C2 = 256) is RE-computed here from the narrow tensor raw2 [rows][64] instead of being written and read back;
+ * its batch statistics (bn3_stats) come from a st_conv1x1_wreg call with y == NULL over the same raw2 / w3_frag.  idn = identity, or
+ * batchnorm(identity; id_*) after a downsample conv.  w3_frag / w1_frag: the fragment-major copies st_conv1x1_wreg uses for the two
+ * layers (C1 -> C2 and C2 -> N, N = 64 | 128).  Bit-identical to st_conv1x1_wreg -> st_bn_act -> st_conv1x1_wreg.  `count` rows went
+ * into every statistic; x_out must not alias an input. */
+typedef struct {
+  const void* raw2; const void* w3_frag; const void* identity; void* x_out; const void* w1_frag; void* y;
+  float* stats; int stats_replicas;
+  const float* bn2_stats; const float* bn2_gamma; const float* bn2_beta; int bn2_replicas;
+  const float* bn3_stats; const float* bn3_gamma; const float* bn3_beta; int bn3_replicas;
+  const float* id_stats; const float* id_gamma; const float* id_beta; int id_replicas;
+  float count; float eps;
+  long rows; int C1, C2, N;
+} st_conv_b2b_desc;
+int st_conv_b2b_supported(int C1, int C2, int N);
+int st_conv_b2b(const st_conv_b2b_desc* d, void* stream);
 /* The activation-stationary sibling for (C, N) = (256, 1024) / (512, 2048) (conv3 of the layer3 / layer4 Bottlenecks): a
  * workgroup keeps its 112 x C rows in LDS (producer's BatchNorm + ReLU applied once per element) and walks all N output
  * channels barrier-free, the epilogue of one 128-channel chunk under the next chunk's MFMAs.  Same descriptor (weights packed with the

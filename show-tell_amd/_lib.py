@@ -47,6 +47,15 @@ class StemConvPoolDesc(C.Structure):
                 ("scale", c_p), ("shift", c_p), ("B", c_i), ("H", c_i), ("W", c_i)]
 
 
+class ConvB2bDesc(C.Structure):
+    _fields_ = [("raw2", c_p), ("w3_frag", c_p), ("identity", c_p), ("x_out", c_p), ("w1_frag", c_p), ("y", c_p),
+                ("stats", c_p), ("stats_replicas", c_i),
+                ("bn2_stats", c_p), ("bn2_gamma", c_p), ("bn2_beta", c_p), ("bn2_replicas", c_i),
+                ("bn3_stats", c_p), ("bn3_gamma", c_p), ("bn3_beta", c_p), ("bn3_replicas", c_i),
+                ("id_stats", c_p), ("id_gamma", c_p), ("id_beta", c_p), ("id_replicas", c_i),
+                ("count", c_f), ("eps", c_f), ("rows", c_l), ("C1", c_i), ("C2", c_i), ("N", c_i)]
+
+
 class BnActDesc(C.Structure):
     _fields_ = [("x", c_p), ("y", c_p), ("res", c_p), ("stats", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("res_stats", c_p), ("res_gamma", c_p),
@@ -102,6 +111,8 @@ _SIGS = {
     "st_conv1x1_wreg": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_conv1x1_kfuse": ([C.POINTER(Conv1x1KfuseDesc), c_p], c_i),
     "st_conv1x1_kfuse_supported": ([c_i, c_i], c_i),
+    "st_conv_b2b": ([C.POINTER(ConvB2bDesc), c_p], c_i),
+    "st_conv_b2b_supported": ([c_i, c_i, c_i], c_i),
     "st_conv1x1_astat_supported": ([c_i, c_i], c_i),
     "st_conv1x1_astat": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_conv1x1_kstream_supported": ([c_i, c_i], c_i),

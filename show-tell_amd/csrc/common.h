@@ -47,6 +47,19 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
+// Scale / shift of a train-mode BatchNorm from a channel's [sum, sumsq].  ONE definition for every kernel that normalises (st_bn_act, the
+// convolution loaders, the fused block-boundary kernels), written with EXPLICIT fused multiply-adds: under -ffp-contract=fast the
+// backend fuses `sumsq * inv - mean * mean` either way round depending on the surrounding code (a `#pragma clang fp contract(off)` does
+// not stop it), two kernels then disagree in the last bit of the scale, and that flips a bf16 rounding about once per million elements --
+// enough to break the bit-for-bit equivalences the tests assert between the fused and the separate forms.
+__device__ __forceinline__ void bn_scale_shift(float sum, float sumsq, float inv_count, float gamma, float beta, float eps, float& sc, float& sh) {
+  const float mean = sum * inv_count;
+  const float var = fmaxf(__builtin_fmaf(-mean, mean, sumsq * inv_count), 0.f);
+  const float s = gamma * rsqrtf(var + eps);
+  sc = s;
+  sh = __builtin_fmaf(-mean, s, beta);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

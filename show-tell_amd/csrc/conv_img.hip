@@ -141,10 +141,7 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
       for (int c = tid; c < C; c += 256) {
         float sm = 0.f, sq = 0.f;
         for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * C + c]; sq += a.in_stats[(size_t)r * 2 * C + C + c]; }
-        const float mean = sm * inv;
-        const float var = fmaxf(sq * inv - mean * mean, 0.f);
-        const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
-        coef[c] = scv; coef[C + c] = a.in_beta[c] - mean * scv;
+        bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[C + c]);
       }
       __syncthreads();
 #pragma unroll
@@ -188,10 +185,7 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
         for (int c = tid; c < C; c += 256) {
           float sm = 0.f, sq = 0.f;
           for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * C + c]; sq += a.in_stats[(size_t)r * 2 * C + C + c]; }
-          const float mean = sm * inv;
-          const float var = fmaxf(sq * inv - mean * mean, 0.f);
-          const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
-          coef[c] = scv; coef[C + c] = a.in_beta[c] - mean * scv;
+          bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[C + c]);
         }
         __syncthreads();
 #pragma unroll
@@ -467,19 +461,13 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
     for (int c = tid; c < K; c += 256) {
       float sm = 0.f, sq = 0.f;
       for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * K + c]; sq += a.in_stats[(size_t)r * 2 * K + K + c]; }
-      const float mean = sm * inv;
-      const float var = fmaxf(sq * inv - mean * mean, 0.f);
-      const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
-      coef[c] = scv; coef[K + c] = a.in_beta[c] - mean * scv;
+      bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[K + c]);
       if constexpr (FUSE) {
         float s2 = 1.f, h2 = 0.f;
         if (rbn) {
           float rm = 0.f, rq = 0.f;
           for (int r = 0; r < a.res_srep; ++r) { rm += a.res_stats[(size_t)r * 2 * K + c]; rq += a.res_stats[(size_t)r * 2 * K + K + c]; }
-          const float m2 = rm * inv;
-          const float v2 = fmaxf(rq * inv - m2 * m2, 0.f);
-          s2 = a.res_gamma[c] * rsqrtf(v2 + a.in_eps);
-          h2 = a.res_beta[c] - m2 * s2;
+          bn_scale_shift(rm, rq, inv, a.res_gamma[c], a.res_beta[c], a.in_eps, s2, h2);
         }
         coef[2 * K + c] = s2; coef[3 * K + c] = h2;
       }
@@ -558,6 +546,7 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
         }
         const size_t off = (size_t)m * a.N + cb;
         bf16_t* dst = a.y + off;
+        if (a.y) {                                     // y == NULL: statistics only (st_conv_b2b recomputes the output where it is consumed)
         if constexpr (NTW == 1) {
           *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         } else {
@@ -565,6 +554,7 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
           for (int h = 0; h < NTW / 2; ++h)
             *reinterpret_cast<u32x4*>(dst + 8 * h) = u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
                                                            pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+        }
         }
       }
     }
@@ -852,10 +842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int c = tid; c < K; c += 256) {
         float sm = 0.f, sq = 0.f;
         for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * K + c]; sq += a.in_stats[(size_t)r * 2 * K + K + c]; }
-        const float mean = sm * inv;
-        const float var = fmaxf(sq * inv - mean * mean, 0.f);
-        const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
-        coef[c] = scv; coef[K + c] = a.in_beta[c] - mean * scv;
+        bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[K + c]);
       }
       __syncthreads();
       float sc[8], sh[8];
@@ -1059,10 +1046,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int c = tid; c < K; c += 256) {
       float sm = 0.f, sq = 0.f;
       for (int r = 0; r < a.f_srep; ++r) { sm += a.f_stats[(size_t)r * 2 * K + c]; sq += a.f_stats[(size_t)r * 2 * K + K + c]; }
-      const float mean = sm * inv;
-      const float var = fmaxf(sq * inv - mean * mean, 0.f);
-      const float scv = a.f_gamma[c] * rsqrtf(var + a.f_eps);
-      coef[c] = scv; coef[K + c] = a.f_beta[c] - mean * scv;
+      bn_scale_shift(sm, sq, inv, a.f_gamma[c], a.f_beta[c], a.f_eps, coef[c], coef[K + c]);
     }
   }
   __syncthreads();
@@ -1323,7 +1307,7 @@ extern "C" int st_conv1x1_wreg_supported(int K, int N) {
 }
 
 extern "C" int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream) {
-  ST_CHECK(d && d->x && d->w_frag && d->y, "st_conv1x1_wreg: null pointer");
+  ST_CHECK(d && d->x && d->w_frag && (d->y || (d->stats && !d->scale)), "st_conv1x1_wreg: null pointer (y may be NULL only when statistics are asked for)");
   PwCfg c;
   ST_CHECK(pw_cfg(d->C, d->N, &c), "st_conv1x1_wreg: unsupported geometry C=%d N=%d", d->C, d->N);
   ST_CHECK(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->stride >= 1, "st_conv1x1_wreg: bad geometry");

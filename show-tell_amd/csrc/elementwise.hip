@@ -44,15 +44,13 @@ template <> struct Vec<float> {
 __device__ __forceinline__ void bn_coeff(const float* stats, int reps, const float* gamma, const float* beta,
                                          const float* rmean, const float* rvar, int C, int c,
                                          float inv_count, float eps, float& sc, float& sh) {
-  float mean, var;
   if (stats) {
     float s = stats[c], ss = stats[C + c];
     for (int r = 1; r < reps; ++r) { s += stats[(size_t)r * 2 * C + c]; ss += stats[(size_t)r * 2 * C + C + c]; }
-    mean = s * inv_count;
-    var = fmaxf(ss * inv_count - mean * mean, 0.f);
-  } else {
-    mean = rmean[c]; var = rvar[c];
+    bn_scale_shift(s, ss, inv_count, gamma[c], beta[c], eps, sc, sh);
+    return;
   }
+  const float mean = rmean[c], var = rvar[c];
   sc = gamma[c] * rsqrtf(var + eps);
   sh = beta[c] - mean * sc;
 }
@@ -144,10 +142,9 @@ template <int N> __device__ __forceinline__ void bn_coeff_vec(const float* stats
   ldf<N>(beta + c, be);
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const float mean = stats ? a[k] * inv_count : a[k];
-    const float var = stats ? fmaxf(b[k] * inv_count - mean * mean, 0.f) : b[k];
-    sc[k] = g[k] * rsqrtf(var + eps);
-    sh[k] = be[k] - mean * sc[k];
+    if (stats) { bn_scale_shift(a[k], b[k], inv_count, g[k], be[k], eps, sc[k], sh[k]); continue; }
+    sc[k] = g[k] * rsqrtf(b[k] + eps);
+    sh[k] = be[k] - a[k] * sc[k];
   }
 }
 

@@ -441,11 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmGroup grp) {
   if (XF) {   // coefficients of the producer's BatchNorm, while the first tile is in flight
     const float inv = 1.0f / a.in_inv_count;   // field carries the row count
     for (int c = tid; c < a.Cin; c += NT) {
-      const float mean = a.in_stats[c] * inv;
-      const float var = fmaxf(a.in_stats[a.Cin + c] * inv - mean * mean, 0.f);
-      const float scv = a.in_gamma[c] * rsqrtf(var + a.in_eps);
-      coef[c] = scv;
-      coef[a.Cin + c] = a.in_beta[c] - mean * scv;
+      bn_scale_shift(a.in_stats[c], a.in_stats[a.Cin + c], inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[a.Cin + c]);
     }
     __syncthreads();
   }

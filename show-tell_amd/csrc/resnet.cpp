@@ -289,7 +289,8 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   // the stem's pool): no reduction launch
   // fz (train): x is the RAW conv3 output of the previous block (conv fz->ci); the loader forms relu(bn(x) + identity) itself, writes
   // it to fz->xout (this block's input / identity) and the previous block's separate normalise pass does not run (st_conv1x1_kfuse)
-  struct FuseIn { int ci; const void* res; int res_ci; void* xout; };
+  // b2b: conv fz->ci itself (64 -> 256) is recomputed too, from its RAW input fz->raw2 (output of conv fz->c2ci): st_conv_b2b
+  struct FuseIn { int ci; const void* res; int res_ci; void* xout; bool b2b; const void* raw2; int c2ci; };
   auto conv = [&](int ci, const void* x, int hin, int win, void* y, const void* eval_res, int eval_relu,
                   int* ho, int* wo, int in_ci = -1, bool keep_rep = true, const FuseIn* fz = nullptr) -> int {
     const ConvL& c = r->convs[ci];
@@ -342,7 +343,22 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
       }
-      if (fz) {
+      if (fz && fz->b2b) {
+        const ConvL& pc = r->convs[fz->ci];
+        const ConvL& c2 = r->convs[fz->c2ci];
+        st_conv_b2b_desc k;
+        memset(&k, 0, sizeof(k));
+        k.raw2 = fz->raw2; k.w3_frag = reinterpret_cast<const char*>(weights) + pc.woff_frag * es; k.identity = fz->res; k.x_out = fz->xout;
+        k.w1_frag = g.w_frag; k.y = y; k.stats = g.stats; k.stats_replicas = g.stats_replicas;
+        k.bn2_stats = stats + tab.soff[fz->c2ci]; k.bn2_gamma = bn_gamma + c2.bnoff; k.bn2_beta = bn_beta + c2.bnoff; k.bn2_replicas = tab.rep[fz->c2ci];
+        k.bn3_stats = stats + tab.soff[fz->ci]; k.bn3_gamma = bn_gamma + pc.bnoff; k.bn3_beta = bn_beta + pc.bnoff; k.bn3_replicas = tab.rep[fz->ci];
+        if (fz->res_ci >= 0) {
+          const ConvL& rc = r->convs[fz->res_ci];
+          k.id_stats = stats + tab.soff[fz->res_ci]; k.id_gamma = bn_gamma + rc.bnoff; k.id_beta = bn_beta + rc.bnoff; k.id_replicas = tab.rep[fz->res_ci];
+        }
+        k.count = tab.count[fz->ci]; k.eps = eps; k.rows = (long)B * hin * win; k.C1 = pc.cin; k.C2 = c.cin; k.N = c.cout;
+        if (st_conv_b2b(&k, stream)) return 1;
+      } else if (fz) {
         const ConvL& pc = r->convs[fz->ci];
         st_conv1x1_kfuse_desc k;
         memset(&k, 0, sizeof(k));
@@ -451,13 +467,15 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   // of the widest tensor (measured 168 -> 125 us per transition at 56 x 56, B = 128).  Wider inputs stay separate: their conv1 needs
   // several channel slices per row (each would re-read both inputs) or, at 1024 channels, is MFMA-bound (measured slower fused).
   static const bool kfuse_env = [] { const char* e = getenv("ST_BLOCK_FUSE"); return !e || atoi(e) != 0; }();
-  struct Pending { bool on; int ci; const void* res; int res_ci; int raw_buf, res_buf; } pend{false, -1, nullptr, -1, 0, 0};
+  static const bool b2b_env = [] { const char* e = getenv("ST_BLOCK_B2B"); return !e || atoi(e) != 0; }();
+  struct Pending { bool on; int ci; const void* res; int res_ci; int raw_buf, res_buf; bool b2b; const void* raw2; int c2ci; } pend{false, -1, nullptr, -1, 0, 0, false, nullptr, -1};
   for (size_t bi = 0; bi < r->blocks.size(); ++bi) {
     const BlockL& b = r->blocks[bi];
     FuseIn fzv; const FuseIn* fz = nullptr;
     if (pend.on) {   // wide[cur] holds the previous block's RAW conv3 output; the buffer that is neither it nor the identity takes x
-      const int freeb = 3 - pend.raw_buf - pend.res_buf;
-      fzv = FuseIn{pend.ci, pend.res, pend.res_ci, wide[freeb]};
+                     // (b2b: conv3's output was never written -- its buffer takes x)
+      const int freeb = pend.b2b ? pend.raw_buf : 3 - pend.raw_buf - pend.res_buf;
+      fzv = FuseIn{pend.ci, pend.res, pend.res_ci, wide[freeb], pend.b2b, pend.raw2, pend.c2ci};
       fz = &fzv;
       cur = freeb;
     }
@@ -489,15 +507,19 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         if (conv(b.ds, xin, h, w, wide[dsb], nullptr, 0, &hd, &wd, bi == 0 ? stem_in : -1)) return 1;
         res = wide[dsb];
       }
-      if (conv(b.c3, narrow[1], h2, w2, wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
-      bool defer = false;
+      bool defer = false, b2b = false;
       if (train && use_img && kfuse_env && bi + 1 < r->blocks.size()) {
         const BlockL& nb = r->blocks[bi + 1];
         const ConvL& n1 = r->convs[nb.c1];
         defer = n1.k == 1 && n1.stride == 1 && n1.cin == 256 && n1.ntw > 0 && !use_astat(n1) && c3.cout == n1.cin &&
                 st_conv1x1_kfuse_supported(n1.cin, n1.cout) == n1.ntw;
+        // the 56 x 56 boundaries: conv3 (64 -> 256) is recomputed inside the fused kernel (st_conv_b2b) and runs here for its statistics only
+        b2b = defer && b2b_env && fuse2 && c3.k == 1 && c3.stride == 1 && c3.ntw > 0 && !use_astat(c3) &&
+              c3.ntw == st_conv1x1_wreg_supported(c3.cin, c3.cout) && n1.ntw == st_conv1x1_wreg_supported(n1.cin, n1.cout) &&
+              st_conv_b2b_supported(c3.cin, c3.cout, n1.cout);
       }
-      if (defer) pend = Pending{true, b.c3, res, b.ds, oth, b.ds >= 0 ? dsb : cur};
+      if (conv(b.c3, narrow[1], h2, w2, b2b ? nullptr : wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
+      if (defer) pend = Pending{true, b.c3, res, b.ds, oth, b.ds >= 0 ? dsb : cur, b2b, narrow[1], b.c2};
       else if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
     } else {
       const ConvL& c1 = r->convs[b.c1];

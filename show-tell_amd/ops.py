@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ST_BF16, ST_F32, BnActDesc, Conv1x1KfuseDesc, Conv1x1WregDesc, Conv3x3ImgDesc, ConvDesc, StemConvPoolDesc,
+from ._lib import (ST_BF16, ST_F32, BnActDesc, ConvB2bDesc, Conv1x1KfuseDesc, Conv1x1WregDesc, Conv3x3ImgDesc, ConvDesc, StemConvPoolDesc,
                    check, lib)
 
 _DT = {torch.float32: ST_F32, torch.bfloat16: ST_BF16}
@@ -265,14 +265,16 @@ def conv1x1_wreg_supported(Cin, N):
     return int(lib().st_conv1x1_wreg_supported(Cin, N))
 
 
-def conv1x1_wreg(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, residual=None, in_bn=None, out=None):
-    """Register-resident-filter 1x1 conv (st_conv1x1_wreg): x (B,H,W,C) bf16 NHWC, w_frag from pack_conv_weight_frag(w (N,C,1,1))."""
+def conv1x1_wreg(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, residual=None, in_bn=None, out=None,
+                 stats_only=False):
+    """Register-resident-filter 1x1 conv (st_conv1x1_wreg): x (B,H,W,C) bf16 NHWC, w_frag from pack_conv_weight_frag(w (N,C,1,1)).
+    stats_only: y == NULL -- only the [sum | sumsq] statistics of the output are produced (returns None)."""
     _dev(x, w_frag, stats, scale, shift, residual, out)
     B, H, W, Cc = x.shape
     if x.dtype != torch.bfloat16:
         raise _lib.ShowTellHipError("conv1x1_wreg is a bf16 kernel")
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    if out is None:
+    if out is None and not stats_only:
         out = torch.empty(B, Ho, Wo, N, device=x.device, dtype=torch.bfloat16)
     d = Conv1x1WregDesc(_p(x), _p(w_frag), _p(out), _p(residual), _p(stats), int(stats_replicas), _p(scale), _p(shift), int(relu),
                         None, None, None, 0.0, 0.0, 0, B, H, W, Cc, N, int(stride))
@@ -306,6 +308,26 @@ def conv1x1_kfuse(raw, identity, w_frag, bn, N=256, id_bn=None, stats=None, stat
         d.id_stats, d.id_gamma, d.id_beta = id_bn["stats"].data_ptr(), id_bn["gamma"].data_ptr(), id_bn["beta"].data_ptr()
         d.id_stats_replicas = int(id_bn.get("replicas", 0))
     check(lib().st_conv1x1_kfuse(C.byref(d), _stream()), "st_conv1x1_kfuse")
+    return x_out, out
+
+
+def conv_b2b(raw2, w3_frag, identity, w1_frag, N, bn2, bn3, count, id_bn=None, eps=1e-5, stats=None, stats_replicas=0, x_out=None, out=None):
+    """st_conv_b2b: x = relu(bn3(conv3(relu(bn2(raw2)))) + identity) (written to x_out), y = conv1(x).  bn2 / bn3 / id_bn = dict(stats,
+    gamma, beta[, replicas]).  Returns (x_out, y)."""
+    _dev(raw2, w3_frag, identity, w1_frag, stats, x_out, out)
+    rows = raw2.numel() // raw2.shape[-1]
+    C1, C2 = raw2.shape[-1], identity.shape[-1]
+    if x_out is None:
+        x_out = torch.empty_like(identity)
+    if out is None:
+        out = torch.empty(*raw2.shape[:-1], N, device=raw2.device, dtype=torch.bfloat16)
+    ib = id_bn or {}
+    d = ConvB2bDesc(_p(raw2), _p(w3_frag), _p(identity), _p(x_out), _p(w1_frag), _p(out), _p(stats), int(stats_replicas),
+                    _p(bn2["stats"]), _p(bn2["gamma"]), _p(bn2["beta"]), int(bn2.get("replicas", 0)),
+                    _p(bn3["stats"]), _p(bn3["gamma"]), _p(bn3["beta"]), int(bn3.get("replicas", 0)),
+                    _p(ib.get("stats")), _p(ib.get("gamma")), _p(ib.get("beta")), int(ib.get("replicas", 0)),
+                    float(count), float(eps), rows, C1, C2, N)
+    check(lib().st_conv_b2b(C.byref(d), _stream()), "st_conv_b2b")
     return x_out, out
 
 

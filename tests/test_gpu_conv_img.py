@@ -356,3 +356,63 @@ def test_conv1x1_kfuse_register_filter_form_equals_bn_act_then_wreg(case):
     np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s0.cpu().numpy(), rtol=2e-3, atol=2e-2 * np.sqrt(n))
     ref = F.conv2d(x_ref.float().cpu().permute(0, 3, 1, 2), w, None, 1, 0).permute(0, 2, 3, 1)
     assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+
+
+# (rows shape, N of the next conv1, identity needs its own BatchNorm)
+B2B_CASES = [((2, 56, 56), 64, False), ((1, 56, 56), 64, True), ((2, 56, 56), 128, False), ((3, 9, 7), 64, True), ((1, 1, 5), 128, False),
+             ((5, 28, 28), 64, False)]
+
+
+@pytest.mark.parametrize("case", B2B_CASES)
+def test_conv_b2b_equals_conv3_bn_act_conv1(case):
+    """st_conv_b2b (conv3 64 -> 256 RE-computed from the narrow tensor, bn3 + identity + ReLU, next conv1 256 -> 64 | 128 in one kernel)
+    against the three-kernel form st_conv1x1_wreg -> st_bn_act -> st_conv1x1_wreg: x_out and y bit for bit; the statistics-only conv3
+    (y == NULL) must produce the same statistics as the storing one."""
+    ops = _ops()
+    shape, N, idbn = case
+    B, H, W = shape
+    C1, C2 = 64, 256
+    assert ops.lib().st_conv_b2b_supported(C1, C2, N) == 1 and ops.lib().st_conv_b2b_supported(C1, C2, 256) == 0
+    g = torch.Generator().manual_seed(B * H + W + N)
+    raw2 = (torch.randn(B, H, W, C1, generator=g) * 1.1 + 0.2).bfloat16().cuda()
+    ident = (torch.randn(B, H, W, C2, generator=g) * (1.0 if idbn else 0.7)).bfloat16().cuda()
+    if not idbn:
+        ident = torch.relu(ident)
+    w3 = (torch.randn(C2, C1, 1, 1, generator=g) / np.sqrt(C1)).bfloat16().float()
+    w1 = (torch.randn(N, C2, 1, 1, generator=g) / np.sqrt(C2)).bfloat16().float()
+    w3f = ops.pack_conv_weight_frag(w3.cuda(), ops.conv1x1_wreg_supported(C1, C2))
+    w1f = ops.pack_conv_weight_frag(w1.cuda(), ops.conv1x1_wreg_supported(C2, N))
+    g2, b2 = (torch.rand(C1, generator=g) + 0.5).cuda(), (torch.randn(C1, generator=g) * 0.3).cuda()
+    g3, b3 = (torch.rand(C2, generator=g) + 0.5).cuda(), (torch.randn(C2, generator=g) * 0.3).cuda()
+    gi, bi = (torch.rand(C2, generator=g) + 0.5).cuda(), (torch.randn(C2, generator=g) * 0.3).cuda()
+    n = float(B * H * W)
+
+    def stats_of(t, C):
+        t2 = t.float().reshape(-1, C)
+        return torch.cat([t2.sum(0), (t2 * t2).sum(0)]).contiguous()
+    s2 = torch.zeros(3, 2 * C1, device="cuda"); s2[1] = stats_of(raw2, C1)
+    si = torch.zeros(2, 2 * C2, device="cuda"); si[1] = stats_of(ident, C2)
+    bn2 = dict(stats=s2, gamma=g2, beta=b2, count=n, replicas=3)
+    # three-kernel form
+    s3 = torch.zeros(4, 2 * C2, device="cuda")
+    raw3 = ops.conv1x1_wreg(raw2, w3f, C2, stats=s3, stats_replicas=4, in_bn=bn2)
+    s3_only = torch.zeros(4, 2 * C2, device="cuda")
+    assert ops.conv1x1_wreg(raw2, w3f, C2, stats=s3_only, stats_replicas=4, in_bn=bn2, stats_only=True) is None
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(s3_only.sum(0).cpu().numpy(), s3.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-2)
+    s3r = s3.sum(0).contiguous()                            # ONE set of bn3 statistics for both forms: bit-exact comparison below
+    kw = dict(res=ident)
+    if idbn:
+        kw.update(res_bn=dict(stats=si[1].contiguous(), gamma=gi, beta=bi))
+    x_ref = ops.bn_act(raw3, g3, b3, stats=s3r, count=n, relu=True, **kw)
+    sy0 = torch.zeros(2 * N, device="cuda")
+    y_ref = ops.conv1x1_wreg(x_ref, w1f, N, stats=sy0)
+    # one kernel
+    s3rep = torch.zeros(2, 2 * C2, device="cuda"); s3rep[1] = s3r
+    sy1 = torch.zeros(4, 2 * N, device="cuda")
+    x, y = ops.conv_b2b(raw2, w3f, ident, w1f, N, dict(stats=s2, gamma=g2, beta=b2, replicas=3), dict(stats=s3rep, gamma=g3, beta=b3, replicas=2), n,
+                        id_bn=dict(stats=si, gamma=gi, beta=bi, replicas=2) if idbn else None, stats=sy1, stats_replicas=4)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x_ref)
+    assert torch.equal(y, y_ref)
+    np.testing.assert_allclose(sy1.sum(0).cpu().numpy(), sy0.cpu().numpy(), rtol=2e-3, atol=2e-2 * np.sqrt(n))
