@@ -45,25 +45,36 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
 }
 
-constexpr int C1 = 64, C2 = 256, SM = 32;                           // conv3 in / out channels, rows per stage
-constexpr int ZPIX = 2 * C1 + 32, XPIX = 2 * C2 + 32;               // padded LDS rows (bytes)
-constexpr int Z_BYTES = SM * ZPIX, X_BYTES = SM * XPIX;
-// LDS: Z[2] | ID[2] | X | coefficient tables (bn2: 2 x 64, bn3: 2 x 256, identity bn: 2 x 256 floats)
-constexpr int B2B_LDS = 2 * Z_BYTES + 3 * X_BYTES + (2 * C1 + 4 * C2) * 4;
+constexpr int SM = 32;                                              // rows per stage
+// LDS: Z[2] | ID[2] (the x tile is formed IN PLACE over the identity tile: a lane reads and writes the same 16 bytes) | coefficient tables
+// (bn2: 2 x C1, bn3: 2 x C2, identity bn: 2 x C2 floats)
+template <int C1, int C2> constexpr int b2b_lds() { return 2 * SM * (2 * C1 + 32) + 2 * SM * (2 * C2 + 32) + (2 * C1 + 4 * C2) * 4; }
 
-template <int N3>
-__global__ __launch_bounds__(256, N3 == 64 ? 2 : 1) void conv_b2b_kernel(B2bArgs a) {   // N3 = 128: 64 more filter registers, one workgroup per CU
-  constexpr int NTW3 = N3 / 64;                                      // conv1: 16-channel tiles per wave (its fragment-major packing)
+// (C1, C2, N3): conv3 C1 -> C2, next conv1 C2 -> N3.  (64, 256, 64 | 128): layer1, two workgroups per CU; (128, 512, 128): layer2 -- both
+// filter banks (2 x 128 KB) in the registers of four waves (256 per wave: one workgroup per CU, the kernel is HBM-bound either way).
+template <int C1, int C2, int N3>
+__global__ __launch_bounds__(256, (C2 == 256 && N3 <= 64) ? 2 : 1) void conv_b2b_kernel(B2bArgs a) {
+  constexpr int NW = 4, NT = 64 * NW;
+  constexpr int ZPIX = 2 * C1 + 32, XPIX = 2 * C2 + 32;              // padded LDS rows (bytes)
+  constexpr int Z_BYTES = SM * ZPIX, X_BYTES = SM * XPIX;
+  constexpr int KS1 = C1 / 32, KS3 = C2 / 32;
+  constexpr int NSL = (C2 / 128) / (NW / 4);                         // conv3 (ntw = 2 packing): 128-channel slices this wave takes a 32-channel part of
+  constexpr bool G2 = N3 > 0;                                        // N3 == 0: no second GEMM -- the kernel ends at x (conv3 + bn3 + identity + ReLU)
+  constexpr int NTW3 = G2 ? N3 / 64 : 1;                             // conv1: 16-channel tiles per wave (= the ntw of its fragment-major packing)
   constexpr int NC3 = 4 * NTW3;
+  constexpr int ZCH = C1 / 8, XCH = C2 / 8;                          // 16-byte chunks per row
+  constexpr int ZRS = NT / ZCH, IRS = NT / XCH;                      // rows per loader pass
+  constexpr int NZ = SM / ZRS, NI = SM / IRS;                        // loads per thread per stage (raw2, identity)
+  static_assert(NZ * ZRS == SM && NI * IRS == SM && NSL >= 1 && NTW3 >= 1, "loader / wave split");
   constexpr int D = 2;                                               // register sets of prefetch
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* zt = smem;                                                   // [2][32][ZPIX]  relu(bn2(raw2))
-  char* idt = smem + 2 * Z_BYTES;                                    // [2][32][XPIX]  identity
-  char* xt = idt + 2 * X_BYTES;                                      // [32][XPIX]     x = relu(bn3(raw3) + identity)
-  float* coef = reinterpret_cast<float*>(xt + X_BYTES);              // sc2[64] sh2[64] | sc3[256] sh3[256] | scr[256] shr[256]
+  char* idt = smem + 2 * Z_BYTES;                                    // [2][32][XPIX]  identity, overwritten in place by x = relu(bn3(raw3) + identity)
+  float* coef = reinterpret_cast<float*>(idt + 2 * X_BYTES);         // sc2[C1] sh2[C1] | sc3[C2] sh3[C2] | scr[C2] shr[C2]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w4 = wid & 3, whalf = wid >> 2;                          // conv3's packing: four waves share a 128-channel slice
   const int r16 = lane & 15, q4 = lane >> 4;
   int mb;
   {
@@ -75,65 +86,70 @@ __global__ __launch_bounds__(256, N3 == 64 ? 2 : 1) void conv_b2b_kernel(B2bArgs
   const bool rbn = a.sr != nullptr;
 
   // ---- filters -> registers (fragment-major: one coalesced 1-KiB load per MFMA operand) ---------------------------------------
-  // conv3 (ntw = 2 packing, 16 tiles x 2 K-steps): this wave's tiles (sl * 4 + wid) * 2 + j, sl = 0, 1 -> channels (sl * 4 + wid) * 32 + 8 q4 + ..
+  // conv3 (ntw = 2 packing, C2 / 16 tiles x KS1 K-steps): this wave's tiles (sl * 4 + w4) * 2 + j, sl = whalf NSL + s
+  //   -> channels (sl * 4 + w4) * 32 + 8 q4 + 4 j + e
   const u32x4* w3l = reinterpret_cast<const u32x4*>(a.w3) + lane;
-  u32x4 w3f[2][2][2];
+  u32x4 w3f[NSL][2][KS1];
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl)
+  for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) w3f[sl][j][ks] = w3l[((size_t)(((sl * 4 + wid) * 2 + j) * 2 + ks)) * 64];
-  // conv1 (ntw = NTW3 packing, N3 / 16 tiles x 8 K-steps): this wave's tiles wid * NTW3 + j
+      for (int ks = 0; ks < KS1; ++ks) w3f[sl][j][ks] = w3l[((size_t)((((whalf * NSL + sl) * 4 + w4) * 2 + j) * KS1 + ks)) * 64];
+  // conv1 (ntw = NTW3 packing, N3 / 16 tiles x KS3 K-steps): this wave's tiles wid * NTW3 + j
   const u32x4* w1l = reinterpret_cast<const u32x4*>(a.w1) + lane;
-  u32x4 w1f[NTW3][8];
+  u32x4 w1f[NTW3][G2 ? KS3 : 1];
+  if constexpr (G2) {
 #pragma unroll
-  for (int j = 0; j < NTW3; ++j)
+    for (int j = 0; j < NTW3; ++j)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) w1f[j][ks] = w1l[((size_t)((wid * NTW3 + j) * 8 + ks)) * 64];
+      for (int ks = 0; ks < KS3; ++ks) w1f[j][ks] = w1l[((size_t)((wid * NTW3 + j) * KS3 + ks)) * 64];
+  }
 
   // ---- loader: raw2 chunk (row tid / 8, chunk tid % 8); identity chunks (row tid / 32 + 8 i, chunk tid % 32) ------------------------
-  const int zc = tid & 7, zr = tid >> 3, ic = tid & 31, ir = tid >> 5;
-  u32x4 pz[D], pi[D][4]; bool okz[D], oki[D][4];
-  auto gload = [&](int set, int k) {
+  const int zc = tid % ZCH, zr = tid / ZCH, ic = tid % XCH, ir = tid / XCH;
+  u32x4 pz[D][NZ], pi[D][NI];
+  auto gload = [&](int set, int k) {       // unconditional clamped loads (rows past the end re-read row M - 1; nothing of them is stored)
     const int g = gs(k);
-    {
-      int m = g * SM + zr;
-      okz[set] = m < a.M && k < a.spb;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      int m = g * SM + zr + ZRS * i;
       m = m < a.M ? m : a.M - 1;
-      pz[set] = *reinterpret_cast<const u32x4*>(a.raw2 + (size_t)m * C1 + zc * 8);
+      pz[set][i] = *reinterpret_cast<const u32x4*>(a.raw2 + (size_t)m * C1 + zc * 8);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = g * SM + ir + 8 * i;
-      oki[set][i] = m < a.M && k < a.spb;
+    for (int i = 0; i < NI; ++i) {
+      int m = g * SM + ir + IRS * i;
       m = m < a.M ? m : a.M - 1;
       pi[set][i] = *reinterpret_cast<const u32x4*>(a.res + (size_t)m * C2 + ic * 8);
     }
   };
   float sc2[8], sh2[8];
   auto lstore = [&](int set, int buf) {
-    u32x4 v = pz[set];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {                                    // relu(bn2(.)): st_bn_act's arithmetic, one rounding
-      const float lo = fmaxf(__uint_as_float(v[d] << 16) * sc2[2 * d] + sh2[2 * d], 0.f);
-      const float hi = fmaxf(__uint_as_float(v[d] & 0xffff0000u) * sc2[2 * d + 1] + sh2[2 * d + 1], 0.f);
-      v[d] = pack_bf16x2(lo, hi);
+    for (int i = 0; i < NZ; ++i) {
+      u32x4 v = pz[set][i];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {                                  // relu(bn2(.)): st_bn_act's arithmetic, one rounding
+        const float lo = fmaxf(__uint_as_float(v[d] << 16) * sc2[2 * d] + sh2[2 * d], 0.f);
+        const float hi = fmaxf(__uint_as_float(v[d] & 0xffff0000u) * sc2[2 * d + 1] + sh2[2 * d + 1], 0.f);
+        v[d] = pack_bf16x2(lo, hi);
+      }
+      *reinterpret_cast<u32x4*>(zt + buf * Z_BYTES + (zr + ZRS * i) * ZPIX + zc * 16) = v;
     }
-    *reinterpret_cast<u32x4*>(zt + buf * Z_BYTES + zr * ZPIX + zc * 16) = v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(idt + buf * X_BYTES + (ir + 8 * i) * XPIX + ic * 16) = pi[set][i];
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(idt + buf * X_BYTES + (ir + IRS * i) * XPIX + ic * 16) = pi[set][i];
   };
 
   gload(0, 0);
   {   // BatchNorm coefficients (replicated statistics summed here), while the first rows are in flight
     const float inv = 1.0f / a.count;
-    for (int c = tid; c < C1; c += 256) {
+    for (int c = tid; c < C1; c += NT) {
       float sm = 0.f, sq = 0.f;
       for (int r = 0; r < a.s2rep; ++r) { sm += a.s2[(size_t)r * 2 * C1 + c]; sq += a.s2[(size_t)r * 2 * C1 + C1 + c]; }
       bn_scale_shift(sm, sq, inv, a.g2[c], a.b2[c], a.eps, coef[c], coef[C1 + c]);
     }
-    for (int c = tid; c < C2; c += 256) {
+    for (int c = tid; c < C2; c += NT) {
       float sm = 0.f, sq = 0.f;
       for (int r = 0; r < a.s3rep; ++r) { sm += a.s3[(size_t)r * 2 * C2 + c]; sq += a.s3[(size_t)r * 2 * C2 + C2 + c]; }
       bn_scale_shift(sm, sq, inv, a.g3[c], a.b3[c], a.eps, coef[2 * C1 + c], coef[2 * C1 + C2 + c]);
@@ -167,24 +183,25 @@ __global__ __launch_bounds__(256, N3 == 64 ? 2 : 1) void conv_b2b_kernel(B2bArgs
     for (int u = 0; u < D; ++u) {
       const int k = k0 + u, buf = u & 1;                             // (D == 2: stage k sits in ring half k & 1 == u)
       const char* zb = zt + buf * Z_BYTES;
-      const char* ib = idt + buf * X_BYTES;
+      char* ib = idt + buf * X_BYTES;
+      char* xt = ib;                                                 // the x tile replaces the identity tile, element for element
       // ---- GEMM 1: raw3 tile = Z (32 x 64) x W3^T -> this wave's 2 x 32 channels --------------------------------------------------
-      f32x4 acc1[2][2][2];
+      f32x4 acc1[2][NSL][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
+        for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc1[i][sl][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS1; ++ks) {
         u32x4 zf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) zf[i] = *reinterpret_cast<const u32x4*>(zb + (16 * i + r16) * ZPIX + ks * 64 + q4 * 16);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int sl = 0; sl < 2; ++sl)
+          for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc1[i][sl][j] = mfma_bf16(w3f[sl][j][ks], zf[i], acc1[i][sl][j]);
       }
@@ -193,8 +210,8 @@ __global__ __launch_bounds__(256, N3 == 64 ? 2 : 1) void conv_b2b_kernel(B2bArgs
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-          const int chb = (sl * 4 + wid) * 32 + 8 * q4;
+        for (int sl = 0; sl < NSL; ++sl) {
+          const int chb = ((whalf * NSL + sl) * 4 + w4) * 32 + 8 * q4;
           const u32x4 idv = *reinterpret_cast<const u32x4*>(ib + (16 * i + r16) * XPIX + chb * 2);
           float sc3[8], sh3[8];
           {
@@ -223,12 +240,13 @@ __global__ __launch_bounds__(256, N3 == 64 ? 2 : 1) void conv_b2b_kernel(B2bArgs
       {
         const int g = gs(k);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = g * SM + ir + 8 * i;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(xt + (ir + 8 * i) * XPIX + ic * 16);
+        for (int i = 0; i < NI; ++i) {
+          const int m = g * SM + ir + IRS * i;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(xt + (ir + IRS * i) * XPIX + ic * 16);
           if (m < a.M && k < a.spb) *reinterpret_cast<u32x4*>(a.xout + (size_t)m * C2 + ic * 8) = v;
         }
       }
+      if constexpr (G2) {
       // ---- GEMM 2: y tile = x (32 x 256) x W1^T -> this wave's 16 NTW3 channels ---------------------------------------------------
       f32x4 acc3[2][NTW3];
 #pragma unroll
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(256, N3 == 64 ? 2 : 1) void conv_b2b_kernel(B2bArgs
 #pragma unroll
         for (int j = 0; j < NTW3; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ks = 0; ks < KS3; ++ks) {
         u32x4 xf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(xt + (16 * i + r16) * XPIX + ks * 64 + q4 * 16);
@@ -264,6 +282,7 @@ __global__ __launch_bounds__(256, N3 == 64 ? 2 : 1) void conv_b2b_kernel(B2bArgs
           }
         }
       }
+      }
       // ---- next stage: its register set -> the other ring half; that set then requests stage k + 1 + D --------------------------
       lstore((u + 1) % D, buf ^ 1);
       gload((u + 1) % D, k + 1 + D);
@@ -271,34 +290,35 @@ __global__ __launch_bounds__(256, N3 == 64 ? 2 : 1) void conv_b2b_kernel(B2bArgs
     }
   }
 
-  if (a.stats) {
+  if (G2 && a.stats) {
     float* sdst = a.stats + (a.srep > 1 ? (size_t)(mb % a.srep) * 2 * N3 : 0);
 #pragma unroll
     for (int c = 0; c < NC3; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
-    float* sred = reinterpret_cast<float*>(smem);                    // [2][N3]; the stage tiles are dead
+    float* sred = reinterpret_cast<float*>(smem);                    // [2][N3]; the stage tiles are dead (2 N3 floats <= the Z ring)
     __syncthreads();
     if (r16 == 0) {
 #pragma unroll
       for (int c = 0; c < NC3; ++c) { sred[cb3 + c] = es[c]; sred[N3 + cb3 + c] = ess[c]; }
     }
     __syncthreads();
-    for (int t = tid; t < 2 * N3; t += 256) atomicAdd(sdst + t, sred[t]);
+    for (int t = tid; t < 2 * N3; t += NT) atomicAdd(sdst + t, sred[t]);
   }
 }
 
-template <int N3>
+template <int C1, int C2, int N3>
 int launch_b2b(B2bArgs& a, hipStream_t st, double flops) {
+  constexpr int lds = b2b_lds<C1, C2>();
   static int attr_set[64] = {}, occ_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b2b_kernel<N3>), hipFuncAttributeMaxDynamicSharedMemorySize, B2B_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b2b_kernel<C1, C2, N3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set[dev] = 1;
   }
   if (!occ_dev[dev]) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_b2b_kernel<N3>), 256, B2B_LDS) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_b2b_kernel<C1, C2, N3>), 256, lds) != hipSuccess || nb < 1) nb = 1;
     occ_dev[dev] = nb > 2 ? 2 : nb;
   }
   a.nstage = (a.M + SM - 1) / SM;
@@ -307,7 +327,7 @@ int launch_b2b(B2bArgs& a, hipStream_t st, double flops) {
   mbs = (a.nstage + a.spb - 1) / a.spb;
   a.mbs = mbs;
   StProfScope prof(21, flops, st);
-  hipLaunchKernelGGL((conv_b2b_kernel<N3>), dim3(mbs), dim3(256), B2B_LDS, st, a);
+  hipLaunchKernelGGL((conv_b2b_kernel<C1, C2, N3>), dim3(mbs), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
@@ -315,10 +335,12 @@ int launch_b2b(B2bArgs& a, hipStream_t st, double flops) {
 
 }  // namespace
 
-extern "C" int st_conv_b2b_supported(int C1_, int C2_, int N3) { return C1_ == C1 && C2_ == C2 && (N3 == 64 || N3 == 128) ? 1 : 0; }
+extern "C" int st_conv_b2b_supported(int C1, int C2, int N3) {
+  return ((C1 == 64 && C2 == 256 && (N3 == 64 || N3 == 128)) || (C1 == 128 && C2 == 512 && N3 == 0)) ? 1 : 0;   // N3 == 0: stops at x_out
+}
 
 extern "C" int st_conv_b2b(const st_conv_b2b_desc* d, void* stream) {
-  ST_CHECK(d && d->raw2 && d->w3_frag && d->identity && d->x_out && d->w1_frag && d->y, "st_conv_b2b: null pointer");
+  ST_CHECK(d && d->raw2 && d->w3_frag && d->identity && d->x_out && (d->N == 0 || (d->w1_frag && d->y)), "st_conv_b2b: null pointer");
   ST_CHECK(st_conv_b2b_supported(d->C1, d->C2, d->N), "st_conv_b2b: unsupported geometry %d -> %d -> %d", d->C1, d->C2, d->N);
   ST_CHECK(d->bn2_stats && d->bn2_gamma && d->bn2_beta && d->bn3_stats && d->bn3_gamma && d->bn3_beta, "st_conv_b2b: bn2 and bn3 are required");
   ST_CHECK(!d->id_stats || (d->id_gamma && d->id_beta), "st_conv_b2b: id_stats comes with id_gamma, id_beta");
@@ -335,6 +357,7 @@ extern "C" int st_conv_b2b(const st_conv_b2b_desc* d, void* stream) {
   a.sr = d->id_stats; a.gr = d->id_gamma; a.br = d->id_beta; a.srrep = rep(d->id_replicas);
   a.count = d->count; a.eps = d->eps; a.M = (int)d->rows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const double flops = 2.0 * (double)d->rows * ((double)C1 * C2 + (double)C2 * d->N);
-  return d->N == 64 ? launch_b2b<64>(a, st, flops) : launch_b2b<128>(a, st, flops);
+  const double flops = 2.0 * (double)d->rows * ((double)d->C1 * d->C2 + (double)d->C2 * d->N);
+  if (d->C1 == 128) return launch_b2b<128, 512, 0>(a, st, flops);
+  return d->N == 64 ? launch_b2b<64, 256, 64>(a, st, flops) : launch_b2b<64, 256, 128>(a, st, flops);
 }

@@ -518,9 +518,27 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
               c3.ntw == st_conv1x1_wreg_supported(c3.cin, c3.cout) && n1.ntw == st_conv1x1_wreg_supported(n1.cin, n1.cout) &&
               st_conv_b2b_supported(c3.cin, c3.cout, n1.cout);
       }
-      if (conv(b.c3, narrow[1], h2, w2, b2b ? nullptr : wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
+      // the 28 x 28 blocks (conv3 128 -> 512): the same recomputation, stopping at the block output -- conv3 runs for its statistics,
+      // st_conv_b2b (N = 0) forms x = relu(bn3(conv3(..)) + identity) from the narrow tensor: the raw 512-channel tensor (103 MB at
+      // B = 128) is neither written nor read
+      const bool lite = !defer && train && use_img && b2b_env && fuse2 && c3.k == 1 && c3.stride == 1 && c3.ntw > 0 && !use_astat(c3) &&
+                        c3.ntw == st_conv1x1_wreg_supported(c3.cin, c3.cout) && st_conv_b2b_supported(c3.cin, c3.cout, 0);
+      if (conv(b.c3, narrow[1], h2, w2, (b2b || lite) ? nullptr : wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
       if (defer) pend = Pending{true, b.c3, res, b.ds, oth, b.ds >= 0 ? dsb : cur, b2b, narrow[1], b.c2};
-      else if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
+      else if (lite) {
+        const ConvL& c2l = r->convs[b.c2];
+        st_conv_b2b_desc k;
+        memset(&k, 0, sizeof(k));
+        k.raw2 = narrow[1]; k.w3_frag = reinterpret_cast<const char*>(weights) + c3.woff_frag * es; k.identity = res; k.x_out = wide[oth];
+        k.bn2_stats = stats + tab.soff[b.c2]; k.bn2_gamma = bn_gamma + c2l.bnoff; k.bn2_beta = bn_beta + c2l.bnoff; k.bn2_replicas = tab.rep[b.c2];
+        k.bn3_stats = stats + tab.soff[b.c3]; k.bn3_gamma = bn_gamma + c3.bnoff; k.bn3_beta = bn_beta + c3.bnoff; k.bn3_replicas = tab.rep[b.c3];
+        if (b.ds >= 0) {
+          const ConvL& rc = r->convs[b.ds];
+          k.id_stats = stats + tab.soff[b.ds]; k.id_gamma = bn_gamma + rc.bnoff; k.id_beta = bn_beta + rc.bnoff; k.id_replicas = tab.rep[b.ds];
+        }
+        k.count = tab.count[b.c3]; k.eps = eps; k.rows = (long)B * h3 * w3; k.C1 = c3.cin; k.C2 = c3.cout; k.N = 0;
+        if (st_conv_b2b(&k, stream)) return 1;
+      } else if (train && bnact(b.c3, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
     } else {
       const ConvL& c1 = r->convs[b.c1];
       const ConvL& c2 = r->convs[b.c2];

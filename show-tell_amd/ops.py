@@ -312,14 +312,14 @@ def conv1x1_kfuse(raw, identity, w_frag, bn, N=256, id_bn=None, stats=None, stat
 
 
 def conv_b2b(raw2, w3_frag, identity, w1_frag, N, bn2, bn3, count, id_bn=None, eps=1e-5, stats=None, stats_replicas=0, x_out=None, out=None):
-    """st_conv_b2b: x = relu(bn3(conv3(relu(bn2(raw2)))) + identity) (written to x_out), y = conv1(x).  bn2 / bn3 / id_bn = dict(stats,
-    gamma, beta[, replicas]).  Returns (x_out, y)."""
+    """st_conv_b2b: x = relu(bn3(conv3(relu(bn2(raw2)))) + identity) (written to x_out), y = conv1(x) (N == 0: no conv1, y is None).
+    bn2 / bn3 / id_bn = dict(stats, gamma, beta[, replicas]).  Returns (x_out, y)."""
     _dev(raw2, w3_frag, identity, w1_frag, stats, x_out, out)
     rows = raw2.numel() // raw2.shape[-1]
     C1, C2 = raw2.shape[-1], identity.shape[-1]
     if x_out is None:
         x_out = torch.empty_like(identity)
-    if out is None:
+    if out is None and N > 0:
         out = torch.empty(*raw2.shape[:-1], N, device=raw2.device, dtype=torch.bfloat16)
     ib = id_bn or {}
     d = ConvB2bDesc(_p(raw2), _p(w3_frag), _p(identity), _p(x_out), _p(w1_frag), _p(out), _p(stats), int(stats_replicas),
