@@ -50,17 +50,20 @@ constexpr int SM = 32;                                              // rows per 
 // (bn2: 2 x C1, bn3: 2 x C2, identity bn: 2 x C2 floats)
 template <int C1, int C2> constexpr int b2b_lds() { return 2 * SM * (2 * C1 + 32) + 2 * SM * (2 * C2 + 32) + (2 * C1 + 4 * C2) * 4; }
 
-// (C1, C2, N3): conv3 C1 -> C2, next conv1 C2 -> N3.  (64, 256, 64 | 128): layer1, two workgroups per CU; (128, 512, 128): layer2 -- both
-// filter banks (2 x 128 KB) in the registers of four waves (256 per wave: one workgroup per CU, the kernel is HBM-bound either way).
-template <int C1, int C2, int N3>
-__global__ __launch_bounds__(256, (C2 == 256 && N3 <= 64) ? 2 : 1) void conv_b2b_kernel(B2bArgs a) {
-  constexpr int NW = 4, NT = 64 * NW;
+// (C1, C2, N3, NW): conv3 C1 -> C2, next conv1 C2 -> N3 (0: none), NW waves per workgroup.  (64, 256, 64 | 128, 4): layer1, two
+// workgroups per CU; (128, 512, 0, 8): layer2 -- eight waves share conv3's 128-KB filter bank (64 registers each), so that two
+// waves per SIMD overlap each other's phases (as four waves with 128 filter registers each, one wave per SIMD, the same kernel
+// took 57 instead of 4x us: every phase of a stage ran alone).
+template <int C1, int C2, int N3, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && C2 == 256 && N3 <= 64) ? 2 : 1) void conv_b2b_kernel(B2bArgs a) {
+  constexpr int NT = 64 * NW;
   constexpr int ZPIX = 2 * C1 + 32, XPIX = 2 * C2 + 32;              // padded LDS rows (bytes)
   constexpr int Z_BYTES = SM * ZPIX, X_BYTES = SM * XPIX;
   constexpr int KS1 = C1 / 32, KS3 = C2 / 32;
   constexpr int NSL = (C2 / 128) / (NW / 4);                         // conv3 (ntw = 2 packing): 128-channel slices this wave takes a 32-channel part of
   constexpr bool G2 = N3 > 0;                                        // N3 == 0: no second GEMM -- the kernel ends at x (conv3 + bn3 + identity + ReLU)
   constexpr int NTW3 = G2 ? N3 / 64 : 1;                             // conv1: 16-channel tiles per wave (= the ntw of its fragment-major packing)
+  static_assert(!G2 || NW == 4, "the second GEMM is split over four waves");
   constexpr int NC3 = 4 * NTW3;
   constexpr int ZCH = C1 / 8, XCH = C2 / 8;                          // 16-byte chunks per row
   constexpr int ZRS = NT / ZCH, IRS = NT / XCH;                      // rows per loader pass
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256, (C2 == 256 && N3 <= 64) ? 2 : 1) void conv_b2b
   }
 }
 
-template <int C1, int C2, int N3>
+template <int C1, int C2, int N3, int NW>
 int launch_b2b(B2bArgs& a, hipStream_t st, double flops) {
   constexpr int lds = b2b_lds<C1, C2>();
   static int attr_set[64] = {}, occ_dev[64] = {};
@@ -313,12 +316,12 @@ int launch_b2b(B2bArgs& a, hipStream_t st, double flops) {
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b2b_kernel<C1, C2, N3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b2b_kernel<C1, C2, N3, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set[dev] = 1;
   }
   if (!occ_dev[dev]) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_b2b_kernel<C1, C2, N3>), 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_b2b_kernel<C1, C2, N3, NW>), 64 * NW, lds) != hipSuccess || nb < 1) nb = 1;
     occ_dev[dev] = nb > 2 ? 2 : nb;
   }
   a.nstage = (a.M + SM - 1) / SM;
@@ -327,7 +330,7 @@ int launch_b2b(B2bArgs& a, hipStream_t st, double flops) {
   mbs = (a.nstage + a.spb - 1) / a.spb;
   a.mbs = mbs;
   StProfScope prof(21, flops, st);
-  hipLaunchKernelGGL((conv_b2b_kernel<C1, C2, N3>), dim3(mbs), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_b2b_kernel<C1, C2, N3, NW>), dim3(mbs), dim3(64 * NW), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
@@ -358,6 +361,6 @@ extern "C" int st_conv_b2b(const st_conv_b2b_desc* d, void* stream) {
   a.count = d->count; a.eps = d->eps; a.M = (int)d->rows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)d->rows * ((double)d->C1 * d->C2 + (double)d->C2 * d->N);
-  if (d->C1 == 128) return launch_b2b<128, 512, 0>(a, st, flops);
-  return d->N == 64 ? launch_b2b<64, 256, 64>(a, st, flops) : launch_b2b<64, 256, 128>(a, st, flops);
+  if (d->C1 == 128) return launch_b2b<128, 512, 0, 8>(a, st, flops);
+  return d->N == 64 ? launch_b2b<64, 256, 64, 4>(a, st, flops) : launch_b2b<64, 256, 128, 4>(a, st, flops);
 }
