@@ -273,6 +273,8 @@ def main():
             prefixes[18 + i_] = ("conv1x1_astat_kernel<%d," % c_,)
         names[20] = "stem_pool_kernel (conv 7x7/2 + statistics + 3x3/2 pool in one kernel, csrc/conv_stem.hip)"
         prefixes[20] = ("stem_pool_kernel<",)
+        names[21] = "conv_b2b_kernel (conv3 recomputed + bn3 + identity + ReLU (+ next conv1) in one pass, csrc/conv_b2b.hip)"
+        prefixes[21] = ("conv_b2b_kernel<",)
         v = max(range(32), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12 if ms[v] > 0 else 0.0
         tot_ms, tot_fl = sum(ms), sum(fl)
