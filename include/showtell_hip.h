@@ -146,6 +146,10 @@ typedef struct {
 } st_conv1x1_kfuse_desc;
 int st_conv1x1_kfuse_supported(int C, int N);
 int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream);
+/* The 1024 -> 256 form as a producer / consumer workgroup (csrc/conv_kfuse8.hip): four waves multiply, four load / normalise / store; same
+ * descriptor (id_stats must be NULL), same results bit for bit.  Measured a wash against st_bn_act + st_conv1x1_kstream (106.7 vs 108.0 us per
+ * layer3 block); st_resnet_forward does not use it. */
+int st_conv1x1_kfuse8(const st_conv1x1_kfuse_desc* d, void* stream);
 /* Block boundary of the 56 x 56 Bottlenecks in one pass over the wide tensors (csrc/conv_b2b.hip; train mode, bf16):
  *   x_out = relu(bn3(conv3(relu(bn2(raw2)))) + idn),   y = conv1_next(x_out)   (+ statistics of y)
  * conv3 (C1 = 64 -> C2 = 256) is RE-computed here from the narrow tensor raw2 [rows][64] instead of being written and read back;

@@ -111,6 +111,7 @@ _SIGS = {
     "st_conv1x1_wreg": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_conv1x1_kfuse": ([C.POINTER(Conv1x1KfuseDesc), c_p], c_i),
     "st_conv1x1_kfuse_supported": ([c_i, c_i], c_i),
+    "st_conv1x1_kfuse8": ([C.POINTER(Conv1x1KfuseDesc), c_p], c_i),
     "st_conv_b2b": ([C.POINTER(ConvB2bDesc), c_p], c_i),
     "st_conv_b2b_supported": ([c_i, c_i, c_i], c_i),
     "st_conv1x1_astat_supported": ([c_i, c_i], c_i),

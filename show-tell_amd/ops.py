@@ -291,7 +291,7 @@ def conv1x1_kfuse_supported(Cin, N):
     return int(lib().st_conv1x1_kfuse_supported(Cin, N))
 
 
-def conv1x1_kfuse(raw, identity, w_frag, bn, N=256, id_bn=None, stats=None, stats_replicas=0, x_out=None, out=None):
+def conv1x1_kfuse(raw, identity, w_frag, bn, N=256, id_bn=None, stats=None, stats_replicas=0, x_out=None, out=None, eight_waves=False):
     """st_conv1x1_kfuse: x = relu(bn(raw) + identity) (written to x_out; identity normalised with id_bn first when given),
     y = conv1x1(x) (C -> N).  bn / id_bn = dict(stats, gamma, beta[, count, eps, replicas]).  Returns (x_out, y)."""
     _dev(raw, identity, w_frag, stats, x_out, out, bn["stats"], bn["gamma"], bn["beta"])
@@ -307,7 +307,10 @@ def conv1x1_kfuse(raw, identity, w_frag, bn, N=256, id_bn=None, stats=None, stat
         _dev(id_bn["stats"], id_bn["gamma"], id_bn["beta"])
         d.id_stats, d.id_gamma, d.id_beta = id_bn["stats"].data_ptr(), id_bn["gamma"].data_ptr(), id_bn["beta"].data_ptr()
         d.id_stats_replicas = int(id_bn.get("replicas", 0))
-    check(lib().st_conv1x1_kfuse(C.byref(d), _stream()), "st_conv1x1_kfuse")
+    if eight_waves:
+        check(lib().st_conv1x1_kfuse8(C.byref(d), _stream()), "st_conv1x1_kfuse8")
+    else:
+        check(lib().st_conv1x1_kfuse(C.byref(d), _stream()), "st_conv1x1_kfuse")
     return x_out, out
 
 

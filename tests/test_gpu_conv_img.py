@@ -280,8 +280,9 @@ def test_conv1x1_astat_matches_conv2d_igemm_and_separate_bn_pass(case):
     assert (y2.float().cpu() - ref2).abs().max().item() <= 1.5e-2 * ref2.abs().max().item()
 
 
+@pytest.mark.parametrize("eight", [False, True])
 @pytest.mark.parametrize("rows_shape", [(4, 14, 14), (1, 9, 13), (3, 7, 5)])
-def test_conv1x1_kfuse_equals_bn_act_then_kstream(rows_shape):
+def test_conv1x1_kfuse_equals_bn_act_then_kstream(rows_shape, eight):
     """st_conv1x1_kfuse = the block-end normalise pass (relu(bn3(raw) + identity)) + conv1 of the next block in one kernel: x_out must
     equal st_bn_act's output bit for bit (same coefficients, same rounding point), y the K-streaming kernel's on that x."""
     ops = _ops()
@@ -301,7 +302,7 @@ def test_conv1x1_kfuse_equals_bn_act_then_kstream(rows_shape):
     s0 = torch.zeros(2 * N, device="cuda")
     y_ref = ops.conv1x1_kstream(x_ref, wf, N, stats=s0)
     s1 = torch.zeros(2, 2 * N, device="cuda")
-    x, y = ops.conv1x1_kfuse(raw, ident, wf, dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=4), stats=s1, stats_replicas=2)
+    x, y = ops.conv1x1_kfuse(raw, ident, wf, dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=4), stats=s1, stats_replicas=2, eight_waves=eight)
     torch.cuda.synchronize()
     assert torch.equal(x, x_ref)
     assert torch.equal(y, y_ref)

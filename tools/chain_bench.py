@@ -4,13 +4,13 @@ banks, freshly written activations), not back to back on one hot problem.  `pyth
 variant 0 = round-1 route (implicit-GEMM conv2 behind a bn_act pass), 1 = image-resident conv2 with bn1 + ReLU in its fill
 (st_conv3x3_img), 2 = that plus conv3 on st_conv1x1_wreg (sums conv2's replicated statistics itself), 3 = conv1 on st_conv1x1_kstream, conv2 image-resident,
 conv3 on st_conv1x1_astat, separate block-end pass; 4 = that with the block-end pass fused into the next conv1 (st_conv1x1_kfuse:
-the round-2 route of the engine inside a stage).  Run under `rocprofv3 --kernel-trace --stats` for per-kernel averages."""
+the four-wave form, measured slower); 5 = the same fusion on the producer / consumer workgroup (st_conv1x1_kfuse8).  Run under `rocprofv3 --kernel-trace --stats` for per-kernel averages."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from showtell_amd import ops
 from showtell_amd._lib import lib
-variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4]
+variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5]
 B, h, dt, NL, dev = 128, 14, torch.bfloat16, 22, "cuda"
 x0 = torch.relu(torch.randn(B, h, h, 1024, device=dev)).to(dt)
 W1 = [(torch.randn(256, 1024, device=dev) / 32).to(dt) for _ in range(NL)]
@@ -39,7 +39,7 @@ s3rs = [torch.zeros(4, 2048, device=dev) for _ in range(2)]
 def fwd(variant):
     x = x0
     for l in range(NL):
-        if variant == 4:
+        if variant >= 4:
             # x holds the previous block's output only for l == 0; afterwards (raw3, ident) of the previous block are pending
             if l == 0:
                 ops.conv1x1_kstream(x, W1k[l], 256, stats=s1r, stats_replicas=16, out=y1)
@@ -47,7 +47,7 @@ def fwd(variant):
             else:
                 xn = xbuf[l & 1]
                 ops.conv1x1_kfuse(y3s[(l - 1) & 1], ident, W1k[l], dict(stats=s3rs[(l - 1) & 1], gamma=g1k, beta=b1k, count=n, replicas=4),
-                                  stats=s1r, stats_replicas=16, x_out=xn, out=y1)
+                                  stats=s1r, stats_replicas=16, x_out=xn, out=y1, eight_waves=(variant == 5))
                 ident = xn
             ops.conv3x3_img(y1, W2i[l], 256, stats=s2r, stats_replicas=16, out=y2, in_bn=dict(stats=s1r, gamma=g256, beta=b256, count=n, replicas=16))
             ops.conv1x1_astat(y2, W3a[l], 1024, stats=s3rs[l & 1], stats_replicas=4, out=y3s[l & 1], in_bn=dict(stats=s2r, gamma=g256, beta=b256, count=n, replicas=16))
