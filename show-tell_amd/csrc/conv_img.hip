@@ -70,8 +70,13 @@ __device__ __forceinline__ void bn_relu_chunk(u32x4& v, const float* sc, const f
 // K loop, half 1's transform + LDS writes ride one 16-byte chunk per K-step under the first half's MFMAs (its loads were issued
 // with half 0's), one barrier between the halves: 4 us of the 7.8 us fill leave the critical path.  The fragment-major filters
 // carry the same K order (layout code of st_conv3x3_img_supported).
-template <int C, int TM, int NTW, int HALVES, bool AFFINE>
+template <int C, int TM, int NTW, int HALVES, bool AFFINE, int MS = 1>
 __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
+  // MS = 2 (C = 64): the four waves are 2 (position halves) x 2 (channel halves).  With one 16-channel tile per wave (NTW = 1) every
+  // ds_read_b128 of a 16-position operand fed ONE MFMA and the kernel ran at the LDS read rate (1080 KB per workgroup at 128 B/clk =
+  // twice its MFMA time); two tiles per wave over half the positions halve that traffic.
+  constexpr int TMW = TM / MS;                // position tiles per wave
+  static_assert(TM % MS == 0 && (MS == 1 || MS == 2) && (MS == 1 || HALVES == 1), "position split");
   constexpr int PIX = 2 * C + 32;            // bytes per LDS pixel row
   constexpr int CS = C / 32;                 // k-steps per filter tap
   constexpr int CSH = CS / HALVES;           // ... per channel half
@@ -99,7 +104,8 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
   IMG_STAMP(0);
   // the first filter fragments are requested before the fill: they land while the band is staged
   const int r16 = lane & 15, q4 = lane >> 4;
-  const int T0 = (nb * 4 + wid) * NTW;                              // first 16-channel tile of this wave
+  const int wn = MS == 1 ? wid : (wid & 1), wm = MS == 1 ? 0 : (wid >> 1);
+  const int T0 = (nb * (4 / MS) + wn) * NTW;                        // first 16-channel tile of this wave
   const u32x4* wl = reinterpret_cast<const u32x4*>(a.w) + lane;     // fragment (T, ks) = wl[(T * KS + ks) * 64]
   constexpr int WQ = ALLW ? KS : CS;                               // (HALVES = 2: two taps of lead)
   u32x4 wq[WQ][NTW];
@@ -211,36 +217,36 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
   IMG_STAMP(2);
 
   // ---- K loop: no barrier from here on ----------------------------------------------------------------------------
-  f32x4 acc[TM][NTW];
+  f32x4 acc[TMW][NTW];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Straight-line K loop (fully unrolled: no loop-carried register shuffling), software-pipelined in source order and
   // pinned with scheduling barriers: step s issues the LDS reads of step s + 1, runs its TM x NTW MFMAs, then re-requests
   // its filter registers for step s + WQ.  The waits the compiler inserts are then counted (lgkmcnt(TM), vmcnt((WQ-1) NTW)).
-  constexpr int TH = TM > 7 ? 7 : TM;                               // tiles addressed from the first base register (16-bit ds offsets)
-  const char* abase = smem + r16 * PIX + q4 * 16;
+  constexpr int TH = TMW > 7 ? 7 : TMW;                             // tiles addressed from the first base register (16-bit ds offsets)
+  const char* abase = smem + (wm * TMW * 16 + r16) * PIX + q4 * 16;
   // K-step s -> (channel half, tap, 32-channel step inside the half): s = (half * 9 + tap) * CSH + cs
-  auto read_a = [&](u32x4 (&fa)[TM], int s) {
+  auto read_a = [&](u32x4 (&fa)[TMW], int s) {
     const int half = s / (9 * CSH), tap = (s / CSH) % 9, cs = half * CSH + s % CSH;
     const char* ab = abase + ((tap / 3) * Wp + tap % 3) * PIX;
     const char* ab2 = ab + TH * 16 * PIX;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TMW; ++i)
       fa[i] = i < TH ? *reinterpret_cast<const u32x4*>(ab + i * 16 * PIX + cs * 64) : *reinterpret_cast<const u32x4*>(ab2 + (i - TH) * 16 * PIX + cs * 64);
   };
-  u32x4 fa0[TM], fa1[TM];
+  u32x4 fa0[TMW], fa1[TMW];
   read_a(fa0, 0);
 #pragma clang loop unroll(full)
   for (int s = 0; s < KS; ++s) {
-    u32x4 (&cur)[TM] = (s & 1) ? fa1 : fa0;
-    u32x4 (&nxt)[TM] = (s & 1) ? fa0 : fa1;
+    u32x4 (&cur)[TMW] = (s & 1) ? fa1 : fa0;
+    u32x4 (&nxt)[TMW] = (s & 1) ? fa0 : fa1;
     constexpr int SPLIT = HALVES == 2 ? KS / 2 : -1;               // first K-step that reads the second channel half
     if (s + 1 < KS && s + 1 != SPLIT) read_a(nxt, s + 1);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) acc[i][j] = mfma_bf16(wq[s % WQ][j], cur[i], acc[i][j]);
     if (s + WQ < KS) {
@@ -273,11 +279,11 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(scv[c]), "+v"(shv[c]));
   }
-  int ho = r0, wo = r16;
+  int ho = r0, wo = r16 + wm * TMW * 16;
   while (wo >= Wp) { wo -= Wp; ++ho; }
   bf16_t* yimg = a.y + (size_t)img * a.H * a.W * a.N + cb;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TMW; ++i) {
     const bool valid = wo < a.W && ho < r0 + rows;
     if (valid) {
       float v[NC];
@@ -312,7 +318,26 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
     float* sdst = a.stats + (a.srep > 1 ? (size_t)(bi % a.srep) * 2 * a.N : 0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
-    block_stats_flush<NC, 64 * NTW>(es, ess, r16 == 0, wid * 16 * NTW + NC * q4, smem, sdst, nb * 64 * NTW, a.N, tid);
+    if constexpr (MS == 1) {
+      block_stats_flush<NC, 64 * NTW>(es, ess, r16 == 0, wid * 16 * NTW + NC * q4, smem, sdst, nb * 64 * NTW, a.N, tid);
+    } else {   // two waves (position halves) hold partials of the same channels: the second adds to what the first parked
+      constexpr int BNLOC = (4 / MS) * 16 * NTW;
+      float* sred = reinterpret_cast<float*>(smem);
+      const int local = wn * 16 * NTW + NC * q4;
+      __syncthreads();
+      if (r16 == 0 && wm == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { sred[local + c] = es[c]; sred[BNLOC + local + c] = ess[c]; }
+      }
+      __syncthreads();
+      if (r16 == 0 && wm == 1) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { sred[local + c] += es[c]; sred[BNLOC + local + c] += ess[c]; }
+      }
+      __syncthreads();
+      const int chan0 = nb * BNLOC;
+      for (int t = tid; t < 2 * BNLOC; t += 256) atomicAdd(sdst + (t < BNLOC ? chan0 + t : a.N + chan0 + t - BNLOC), sred[t]);
+    }
   }
   IMG_STAMP(4);
 #undef IMG_STAMP
@@ -327,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 template <int C, int TM, int NTW, int HALVES, bool AFFINE>
 __global__ __launch_bounds__(256, 2) void conv3x3_img_kernel_occ2(ImgArgs a) {
-  conv3x3_img_body<C, TM, NTW, HALVES, AFFINE>(a);
+  conv3x3_img_body<C, TM, NTW, HALVES, AFFINE, (C == 64 ? 2 : 1)>(a);
 }
 
 // =====================================================================================================================
@@ -1150,7 +1175,7 @@ struct ImgCfg { int tm, ntw; };
 // the instantiations: (C, TM, NTW)
 inline bool img_cfg(int C, int N, ImgCfg* c) {
   switch (C) {
-    case 64:  *c = ImgCfg{15, 1}; return N % 64 == 0;
+    case 64:  *c = ImgCfg{16, 2}; return N % 64 == 0;    // 2 x 2 waves (position halves x 32-channel halves): conv3x3_img_body MS = 2
     case 128: *c = ImgCfg{14, 2}; return N % 128 == 0;
     case 256: *c = ImgCfg{14, 2}; return N % 128 == 0;
     case 512: *c = ImgCfg{4, 2};  return N % 128 == 0;
@@ -1208,13 +1233,13 @@ extern "C" int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream) {
   a.B = d->B; a.H = d->H; a.W = d->W; a.N = d->N; a.Wp = d->W + 2;
   a.R = 16 * c.tm / a.Wp; if (a.R > d->H) a.R = d->H;
   a.bands = (d->H + a.R - 1) / a.R;
-  a.nbn = d->N / (64 * c.ntw);
+  a.nbn = d->C == 64 ? d->N / (32 * c.ntw) : d->N / (64 * c.ntw);   // C = 64: two channel waves per workgroup (position split)
   a.stamps = st_debug_stamps_ptr();
   const int lds = (16 * c.tm + 2 * a.Wp + 2) * (2 * d->C + 32) + 2 * d->C * (int)sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * d->B * d->H * d->W * (double)d->N * 9.0 * d->C;
   switch (d->C) {
-    case 64:  return launch_img<64, 15, 1, 1>(a, lds, st, flops);
+    case 64:  return launch_img<64, 16, 2, 1>(a, lds, st, flops);
     case 128: return launch_img<128, 14, 2, 1>(a, lds, st, flops);
     case 256: return launch_img<256, 14, 2, 2>(a, lds, st, flops);
     case 512: return launch_img<512, 4, 2, 1>(a, lds, st, flops);
