@@ -1267,7 +1267,7 @@ inline bool pw_cfg(int K, int N, PwCfg* c) {
     case 64:  *c = N == 64 ? PwCfg{1, 4} : PwCfg{2, 4}; return N == 64 || n128;
     case 128: *c = n128 ? PwCfg{2, 2} : PwCfg{1, 2}; return true;
     case 256: *c = n128 ? PwCfg{2, 4} : PwCfg{1, 2}; return true;
-    case 512: *c = PwCfg{1, 2}; return true;
+    case 512: *c = n128 ? PwCfg{2, 2} : PwCfg{1, 2}; return true;   // (2, 2): half the channel slices (each re-reads the rows): 30.8 -> 28.5, 48.2 -> 44.8 us
   }
   return false;
 }
@@ -1465,7 +1465,7 @@ int kfuse_wreg(const st_conv1x1_kfuse_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)d->rows * d->N * d->C;
 #define KF_CASE(KK, NT, TS, DD) if (d->C == KK && c.ntw == NT && c.tms == TS) return launch_pw___<KK, NT, TS, DD, false, false, true>(a, st, flops, true)
-  KF_CASE(256, 1, 2, 3); KF_CASE(256, 2, 4, 2); KF_CASE(512, 1, 2, 2);
+  KF_CASE(256, 1, 2, 3); KF_CASE(256, 2, 4, 2); KF_CASE(512, 1, 2, 2); KF_CASE(512, 2, 2, 2);
 #undef KF_CASE
   st_set_error("st_conv1x1_kfuse: no fused kernel for C=%d N=%d", d->C, d->N);
   return 1;
@@ -1475,7 +1475,7 @@ int kfuse_wreg(const st_conv1x1_kfuse_desc* d, void* stream) {
 extern "C" int st_conv1x1_kfuse_supported(int C, int N) {
   if (C == 1024 && N == 256) return 4;
   PwCfg c;
-  if ((C == 256 || C == 512) && pw_cfg(C, N, &c) && ((C == 256 && ((c.ntw == 1 && c.tms == 2) || (c.ntw == 2 && c.tms == 4))) || (C == 512 && c.ntw == 1 && c.tms == 2))) return c.ntw;
+  if ((C == 256 || C == 512) && pw_cfg(C, N, &c) && ((C == 256 && ((c.ntw == 1 && c.tms == 2) || (c.ntw == 2 && c.tms == 4))) || (C == 512 && c.ntw <= 2 && c.tms == 2))) return c.ntw;
   return 0;
 }
 
