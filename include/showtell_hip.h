@@ -136,7 +136,8 @@ int st_conv1x1_kstream(const st_conv1x1_wreg_desc* d, void* stream);
  *   y     = x_out (*) w_frag (1x1 fragment-major weights, layout code st_conv1x1_kfuse_supported(C, N)),  stats += [sum | sumsq] of y
  * raw / identity / x_out: [rows][C] bf16 (x_out must not alias raw or identity), y: [rows][N] bf16.  Replaces one st_bn_act pass +
  * the conv1 launch.  C = 256 / 512 (layer1 / layer2 and the first conv1 of layer2 / layer3): the register-resident-filter kernel's
- * loader, same weights as st_conv1x1_wreg; C = 1024 -> N = 256: the K-streaming form (id_stats must be NULL). */
+ * loader, same weights as st_conv1x1_wreg; C = 1024 -> N = 256: the K-streaming form (id_stats must be NULL; measured slower than the
+ * separate pass, compiled only under ST_EXPERIMENTAL). */
 typedef struct {
   const void* raw; const void* identity; void* x_out; const void* w_frag; void* y;
   float* stats; int stats_replicas;
@@ -149,7 +150,9 @@ int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream);
 /* The 1024 -> 256 form as a producer / consumer workgroup (csrc/conv_kfuse8.hip): four waves multiply, four load / normalise / store; same
  * descriptor (id_stats must be NULL), same results bit for bit.  Measured a wash against st_bn_act + st_conv1x1_kstream (106.7 vs 108.0 us per
  * layer3 block); st_resnet_forward does not use it. */
+#ifdef ST_EXPERIMENTAL   /* `make EXPERIMENTAL=1`: not part of the product library */
 int st_conv1x1_kfuse8(const st_conv1x1_kfuse_desc* d, void* stream);
+#endif
 /* Block boundary of the 56 x 56 Bottlenecks in one pass over the wide tensors (csrc/conv_b2b.hip; train mode, bf16):
  *   x_out = relu(bn3(conv3(relu(bn2(raw2)))) + idn),   y = conv1_next(x_out)   (+ statistics of y)
  * conv3 (C1 = 64 -> C2 = 256) is RE-computed here from the narrow tensor raw2 [rows][64] instead of being written and read back;

@@ -186,7 +186,14 @@ class ShowTellHipError(RuntimeError):
 
 def declared_symbols():
     """Every entry point include/showtell_hip.h declares (kept in sync by tests/test_abi.py)."""
-    return sorted(list(_SIGS.keys()) + ["st_last_error"])
+    return sorted([k for k in _SIGS if k not in _EXPERIMENTAL] + ["st_last_error"])
+
+
+_EXPERIMENTAL = ("st_conv1x1_kfuse8",)     # measured, not routed: absent from the product build
+
+
+def has_symbol(name):
+    return hasattr(lib(), name)
 
 
 def lib():
@@ -203,6 +210,8 @@ def lib():
         L.st_last_error.restype = C.c_char_p
         L.st_last_error.argtypes = []
         for name, (args, res) in _SIGS.items():
+            if name in _EXPERIMENTAL and not hasattr(L, name):
+                continue                            # `make EXPERIMENTAL=1` builds only (csrc/Makefile)
             fn = getattr(L, name)
             fn.argtypes, fn.restype = args, res
         _lib = L

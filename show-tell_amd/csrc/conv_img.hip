@@ -986,6 +986,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef AS_STAMP
 }
 
+#ifdef ST_EXPERIMENTAL   // measured slower than st_bn_act + st_conv1x1_kstream: kept for A/B runs, not in the product build
 // =====================================================================================================================
 // conv1 of a Bottleneck FUSED WITH THE PREVIOUS BLOCK'S END: x = relu(bn3(raw3) + identity) is what conv1 (1024 -> 256)
 // reads, and in torchvision's graph it is also the next identity.  Here the K-streaming kernel's loader forms x itself --
@@ -1148,6 +1149,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     block_stats_flush<NC, 64 * NTW>(es, ess, r16 == 0, wid * 16 * NTW + NC * q4, smem, sdst, 0, N, tid);
   }
 }
+
+#endif  // ST_EXPERIMENTAL
 
 // ---- fragment-major filter bank ---------------------------------------------------------------------------------
 // out[((T * KS + ks) * 64 + lane) * 8 + j], T = 16-channel tile, ks = 32-deep K step (k = tap * Cin + c), lane = (q4, r16):
@@ -1473,7 +1476,9 @@ int kfuse_wreg(const st_conv1x1_kfuse_desc* d, void* stream) {
 }  // namespace
 
 extern "C" int st_conv1x1_kfuse_supported(int C, int N) {
+#ifdef ST_EXPERIMENTAL
   if (C == 1024 && N == 256) return 4;
+#endif
   PwCfg c;
   if ((C == 256 || C == 512) && pw_cfg(C, N, &c) && ((C == 256 && ((c.ntw == 1 && c.tms == 2) || (c.ntw == 2 && c.tms == 4))) || (C == 512 && c.ntw <= 2 && c.tms == 2))) return c.ntw;
   return 0;
@@ -1485,6 +1490,10 @@ extern "C" int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream) {
            "st_conv1x1_kfuse: bad rows / count / replicas");
   ST_CHECK(!d->id_stats || (d->id_gamma && d->id_beta && d->id_stats_replicas >= 0 && d->id_stats_replicas <= 1024), "st_conv1x1_kfuse: id_stats comes with id_gamma, id_beta");
   if (d->C == 256 || d->C == 512) return kfuse_wreg(d, stream);
+#ifndef ST_EXPERIMENTAL
+  st_set_error("st_conv1x1_kfuse: unsupported geometry C=%d N=%d (the 1024-channel form needs a `make EXPERIMENTAL=1` build)", d->C, d->N);
+  return 1;
+#else
   ST_CHECK(!d->id_stats, "st_conv1x1_kfuse: the 1024-channel form takes a normalised identity");
   ST_CHECK(d->C == 1024 && d->N == 256, "st_conv1x1_kfuse: unsupported geometry C=%d N=%d", d->C, d->N);
   KfArgs a;
@@ -1508,6 +1517,7 @@ extern "C" int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream) {
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
+#endif
 }
 
 // 4: supported (the `ntw` of the fragment-major weights); 0: use st_conv

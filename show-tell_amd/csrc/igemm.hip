@@ -497,6 +497,7 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 
+#ifdef ST_EXPERIMENTAL   // single-buffer form: measured slower inside the network, `make EXPERIMENTAL=1` only
 __global__ __launch_bounds__(256) void igemm_s3_kernel(IgemmGroup grp) {
   typedef bf16_t T;
   const IgemmArgs& a = grp.g[blockIdx.y];
@@ -610,6 +611,8 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(IgemmGroup grp) {
   }
   igemm_epilogue<T, BM, BN, WM, WN>(a, acc, smem, bm, bn, tid);
 }
+
+#endif  // ST_EXPERIMENTAL
 
 // Same block shape with DMA tiles in flight ACROSS the barrier: three 16 KiB buffers of 32-deep K tiles (A 128x64 B + B 128x64 B),
 // tile kt+2 is issued right after the barrier that publishes tile kt, one raw barrier per K tile, counted vmcnt.
@@ -759,7 +762,11 @@ int launch_s3(IgemmArgs* arr, int n, hipStream_t st, bool pipelined = false) {
     }
   }
   if (pipelined) hipLaunchKernelGGL(igemm_s3b_kernel, dim3(a.nbm * a.nbn, n), dim3(256), lds, st, grp);
+#ifdef ST_EXPERIMENTAL
   else hipLaunchKernelGGL(igemm_s3_kernel, dim3(a.nbm * a.nbn, n), dim3(256), lds, st, grp);
+#else
+  else { st_set_error("the single-buffer small-block kernel (ST_IGEMM_S3=1|3) needs a `make EXPERIMENTAL=1` build"); return 1; }
+#endif
   if (prof) {
     (void)hipEventRecord(rec.e1, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -42,6 +42,8 @@ class _FlatOptimizer:
                     view = self.flat_grad[o:o + p.numel()].view(p.shape)
                     if old_grad is not None:
                         view.copy_(old_grad.to(view.device))
+                    else:
+                        view.zero_()               # set_to_none: the slice still holds the previous step's gradient
                     p.grad = view
             return
         dev = params[0].device
@@ -90,6 +92,9 @@ class _FlatOptimizer:
     def state_dict(self):
         """{'state': {i: {<per-tensor buffers>}}, 'param_groups': [{..., 'params': [0..n-1]}]} exactly as
         torch.optim.SGD / Adam write it, so a checkpoint written here loads into the reference's optimizer and back."""
+        owner = getattr(self, "_pending_owner", None)
+        if owner is not None:                      # a pipelined Trainer defers optimizer.step() by one step: apply it first
+            owner.flush()
         state = {}
         if self.flat is not None and self.steps > 0:
             flat_state = self._state()
@@ -127,8 +132,9 @@ class _FlatOptimizer:
         self._restore_hyper(sd)
         state = sd["state"]
         flat_state = self._state()
-        if state and all(isinstance(k, str) for k in state):
-            # round-1 flat layout: whole-buffer tensors keyed by name
+        if state and all(isinstance(k, str) and not k.isdigit() for k in state):
+            # round-1 flat layout: whole-buffer tensors keyed by NAME ('momentum_buffer', 'exp_avg', ..); a torch.optim state whose
+            # integer keys were stringified ('0', '1', ..: JSON round trips) takes the per-parameter path below
             for k, v in state.items():
                 if k not in flat_state or flat_state[k].numel() != v.numel():
                     raise ValueError("flat optimizer state %r does not match this optimizer" % (k,))

@@ -53,6 +53,14 @@ def broadcast_state(modules, optimizer=None, src=0):
                     t.data.copy_(v.reshape(()))
                 else:
                     dist.broadcast(t.data, src)
+                # the write went through `.data`: bump the version counter so that caches keyed on (version, data_ptr) -- the
+                # backbone's packed bf16 / fragment-major filter copies (cnn.py:pack_weights), the optimizer's bf16 shadows --
+                # see that the tensor changed even when a forward had already run on this rank's own initial weights
+                torch.autograd.graph.increment_version(t)
+            bb = getattr(m, "_bb", None)              # frozen backbone: drop the packed copies outright (re-packed on the next forward)
+            if bb is not None:
+                bb.packed = None
+                bb.packed_key = None
     if optimizer is not None:
         optimizer._sync_shadow(initial=True)         # the bf16 copies the kernels read
 

@@ -50,6 +50,7 @@ class Trainer:
         if world_size > 1:
             broadcast_state([cnn, rnn], optimizer)         # replicas start from rank 0's weights and BN buffers
         self.pending = False
+        optimizer._pending_owner = self                    # optimizer.state_dict() / utils.create_checkpoint flush the deferred step
         self._pre = []        # FIFO of (images, pooled features, event): backbone forwards issued ahead on the side streams
         self._side = []
         self._rr = 0

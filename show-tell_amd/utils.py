@@ -17,7 +17,9 @@ def create_checkpoint(cnn, rnn, optimizer, epoch, step, train_loss, params, trai
     `trainer`: a showtell_amd.train.Trainer whose last optimizer.step() may still be pending (it is applied after the NEXT
     step's frozen backbone so that the gradient all-reduce hides behind it); it is flushed first so that the file holds what
     the reference's loop would hold at this point.'''
-    if trainer is not None:
+    if trainer is None:
+        trainer = getattr(optimizer, '_pending_owner', None)   # a Trainer registers itself on its optimizer (train.py): the
+    if trainer is not None:                                    # reference call signature flushes the deferred update too
         trainer.flush()
     model_file = 'model_' + str(epoch) + '.ckpt'
     metrics_file = 'model_' + str(epoch) + '_metrics.ckpt'

@@ -288,6 +288,9 @@ def test_conv1x1_kfuse_equals_bn_act_then_kstream(rows_shape, eight):
     ops = _ops()
     B, H, W = rows_shape
     C, N = 1024, 256
+    from showtell_amd import _lib
+    if ops.conv1x1_kfuse_supported(C, N) == 0 or (eight and not _lib.has_symbol("st_conv1x1_kfuse8")):
+        pytest.skip("the 1024-channel fused forms are measured-and-unrouted kernels: `make EXPERIMENTAL=1` builds only")
     g = torch.Generator().manual_seed(B * H + W)
     raw = (torch.randn(B, H, W, C, generator=g) * 1.3 + 0.1).bfloat16().cuda()
     ident = torch.relu(torch.randn(B, H, W, C, generator=g)).bfloat16().cuda()
