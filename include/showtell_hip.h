@@ -111,8 +111,10 @@ int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream);
  * (conv3 / downsample of torchvision's Bottleneck and the narrow conv1s, reference cnn.py:46; csrc/conv_img.hip).
  * x: [B][Hin][Win][C] bf16 (dense), y: [B][Ho][Wo][N] bf16 with Ho = (Hin - 1) / stride + 1;
  * w_frag: st_pack_conv_weight_frag(.., KH = KW = 1, ntw = st_conv1x1_wreg_supported(C, N)).
- * in_stats / stats / scale / shift / relu as in st_conv3x3_img_desc; residual must be NULL (reserved: an epilogue that adds a
- * residual stays with st_conv).  y may be NULL in train mode (stats given): only the statistics of the output are produced.
+ * in_stats / stats / scale / shift / relu as in st_conv3x3_img_desc.  residual ([B][Ho][Wo][N] bf16, the Bottleneck's identity): the
+ * eval-mode conv3 epilogue y = relu(conv(x) * scale + shift + residual) -- needs scale / shift, stride 1, no statistics (st_conv1x1_wreg
+ * and the stride-1 forms of st_conv1x1_astat; st_conv1x1_kstream has none).  y may be NULL in train mode (stats given): only the
+ * statistics of the output are produced.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const void* x; const void* w_frag; void* y; const void* residual;
@@ -169,6 +171,8 @@ typedef struct {
   float count; float eps;
   long rows; int C1, C2, N;
 } st_conv_b2b_desc;
+/* Layout contract (the kernel indexes the fragments with fixed tile permutations): w3_frag packed with ntw = 2, w1_frag with
+ * ntw = N / 64 -- what st_conv1x1_wreg_supported returns for these layers today; a caller that packs another ntw gets wrong channels. */
 int st_conv_b2b_supported(int C1, int C2, int N);
 int st_conv_b2b(const st_conv_b2b_desc* d, void* stream);
 /* The activation-stationary sibling for (C, N) = (256, 1024) / (512, 2048) (conv3 of the layer3 / layer4 Bottlenecks): a
@@ -322,6 +326,10 @@ int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cout, int* k, 
 /* frag_ntw > 0: layer i also needs a fragment-major copy of its filters at element offset frag_weight_offset
  * (st_pack_conv_weight_frag(.., ntw = frag_ntw)) for the image-resident kernel; 0: none. */
 size_t st_resnet_workspace_bytes(const st_resnet* r, int B, int H, int W);
+/* Test / diagnosis aid: with a buffer set, every st_resnet_forward on this handle also copies each residual block's output
+ * ([B][h][w][C] in the compute dtype, NHWC) into it, block after block in network order (ResNet-101 @224: 33 blocks, 17.9 MB per
+ * image in bf16); buf = NULL switches it off.  The block-by-block parity test feeds these to the oracle one block at a time. */
+int st_resnet_set_taps(st_resnet* r, void* buf, size_t bytes);
 int st_resnet_forward(const st_resnet* r, const float* images_nchw, int B, int H, int W,
                       const void* weights, const float* bn_gamma, const float* bn_beta,
                       float* bn_running_mean, float* bn_running_var,

@@ -449,6 +449,26 @@ def _bn2d(params, x, bn, train, momentum=0.1, eps=1e-5):
     return y
 
 
+def block_forward(params, x, version, li, bi, train=False):
+    """ONE residual block of torchvision's ResNet (BasicBlock / Bottleneck.forward, v1.5: stride on the 3x3), block `bi` of
+    layer{li + 1}: the body of backbone_forward's loop, callable on its own so that a kernel test can feed it the HIP path's
+    own output of the previous block (block-by-block parity: no cross-block amplification of storage rounding)."""
+    kind, _ = RESNET_SPECS[version]
+    p = f"model.{4 + li}.{bi}"
+    s = (1 if li == 0 else 2) if bi == 0 else 1
+    idt = x
+    if kind == "bottleneck":
+        o = F.relu(_bn2d(params, F.conv2d(x, params[p + ".conv1.weight"]), p + ".bn1", train))
+        o = F.relu(_bn2d(params, F.conv2d(o, params[p + ".conv2.weight"], None, s, 1), p + ".bn2", train))
+        o = _bn2d(params, F.conv2d(o, params[p + ".conv3.weight"]), p + ".bn3", train)
+    else:
+        o = F.relu(_bn2d(params, F.conv2d(x, params[p + ".conv1.weight"], None, s, 1), p + ".bn1", train))
+        o = _bn2d(params, F.conv2d(o, params[p + ".conv2.weight"], None, 1, 1), p + ".bn2", train)
+    if p + ".downsample.0.weight" in params:
+        idt = _bn2d(params, F.conv2d(x, params[p + ".downsample.0.weight"], None, s), p + ".downsample.1", train)
+    return F.relu(o + idt)
+
+
 def backbone_forward(params, x, version=101, train=False, avgpool=True, taps=None):
     """torchvision resnet children()[:-1] (cnn.py:34) or [:-2] (cnn_attn.py:34).
 
@@ -466,21 +486,9 @@ def backbone_forward(params, x, version=101, train=False, avgpool=True, taps=Non
         taps["pool"] = x
     for li, nb in enumerate(blocks):
         for bi in range(nb):
-            p = f"model.{4 + li}.{bi}"
-            s = (1 if li == 0 else 2) if bi == 0 else 1
-            idt = x
-            if kind == "bottleneck":
-                o = F.relu(_bn2d(params, F.conv2d(x, params[p + ".conv1.weight"]), p + ".bn1", train))
-                o = F.relu(_bn2d(params, F.conv2d(o, params[p + ".conv2.weight"], None, s, 1), p + ".bn2", train))
-                o = _bn2d(params, F.conv2d(o, params[p + ".conv3.weight"]), p + ".bn3", train)
-            else:
-                o = F.relu(_bn2d(params, F.conv2d(x, params[p + ".conv1.weight"], None, s, 1), p + ".bn1", train))
-                o = _bn2d(params, F.conv2d(o, params[p + ".conv2.weight"], None, 1, 1), p + ".bn2", train)
-            if p + ".downsample.0.weight" in params:
-                idt = _bn2d(params, F.conv2d(x, params[p + ".downsample.0.weight"], None, s), p + ".downsample.1", train)
-            x = F.relu(o + idt)
+            x = block_forward(params, x, version, li, bi, train)
             if taps is not None:
-                taps[p] = x
+                taps[f"model.{4 + li}.{bi}"] = x
     if avgpool:
         x = F.adaptive_avg_pool2d(x, 1)
     return x

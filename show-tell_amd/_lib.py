@@ -172,6 +172,7 @@ _SIGS = {
     "st_resnet_bn_channels": ([c_p], C.c_size_t),
     "st_resnet_conv_info": ([c_p, c_i] + [C.POINTER(c_i)] * 6 + [C.POINTER(C.c_size_t)] * 2 + [C.POINTER(c_i), C.POINTER(C.c_size_t), C.POINTER(c_i)], c_i),
     "st_resnet_workspace_bytes": ([c_p, c_i, c_i, c_i], C.c_size_t),
+    "st_resnet_set_taps": ([c_p, c_p, C.c_size_t], c_i),
     "st_resnet_forward": ([c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, C.c_size_t,
                            c_p, c_p, c_i, c_p, c_p], c_i),
     "st_resnet_update_running": ([c_p, c_p, c_p, c_p, c_f, c_p], c_i),

@@ -173,6 +173,36 @@ class _Backbone:
                                                      inf["cout"], inf["cin"], inf["k"], inf["k"], inf["ntw"], st), "st_pack_conv_weight_frag")
         self.packed_key = key
 
+    def block_outputs(self, x, train):
+        """Diagnosis / test aid (st_resnet_set_taps): one forward that also returns every residual block's output as the engine
+        stored it -- a list of (B, h, w, C) NHWC tensors in the compute dtype, in network order."""
+        self._ensure_handle()
+        B, _, H, W = x.shape
+        h = ((H + 6 - 7) // 2 + 1 - 1) // 2 + 1
+        w = ((W + 6 - 7) // 2 + 1 - 1) // 2 + 1
+        kind, nblocks = _SPECS[self.version]
+        exp = 4 if kind == "bottleneck" else 1
+        shapes = []
+        for li, (planes, nb) in enumerate(zip([64, 128, 256, 512], nblocks)):
+            for bi in range(nb):
+                if li > 0 and bi == 0:
+                    h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                shapes.append((B, h, w, planes * exp))
+        n = sum(a * b * c * d for a, b, c, d in shapes)
+        buf = torch.empty(n, device=x.device, dtype=self.dtype)
+        check(lib().st_resnet_set_taps(self.handle, C.c_void_p(buf.data_ptr()), buf.numel() * buf.element_size()), "st_resnet_set_taps")
+        try:
+            pooled, _ = self.forward(x, train, True, False)
+            torch.cuda.synchronize()
+        finally:
+            check(lib().st_resnet_set_taps(self.handle, None, 0), "st_resnet_set_taps")
+        outs, o = [], 0
+        for sh in shapes:
+            k = sh[0] * sh[1] * sh[2] * sh[3]
+            outs.append(buf[o:o + k].view(sh))
+            o += k
+        return outs, pooled
+
     def forward(self, x, train, want_pooled, want_ncp, pooled_dtype=torch.float32):
         if not x.is_cuda:
             raise _lib.ShowTellHipError("ResNet.forward needs a HIP device tensor (no CPU fallback in the MI355X build)")

@@ -378,6 +378,8 @@ struct PwArgs {
   // relu(bn(x) + bn_r(res)) (bn_r = identity when res_stats is NULL), feeds it to the MFMAs and writes it ONCE to xout
   const bf16_t* res; bf16_t* xout;
   const float* res_stats; const float* res_gamma; const float* res_beta; int res_srep;
+  // RES (eval mode, conv3 of a Bottleneck): y = relu(conv(x) * scale + shift + identity); identity: [M][N]
+  const bf16_t* idn;
 };
 
 // relu(x * sc + sh) on 8 bf16 (one 16-byte chunk), rounded once: the same arithmetic as bn_act's pass
@@ -390,8 +392,9 @@ __device__ __forceinline__ void bn_relu_chunk(u32x4& v, const float* sc, const f
   }
 }
 
-template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE, bool FUSE = false>
+template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE, bool FUSE = false, bool RES = false>
 __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
+  static_assert(!RES || (AFFINE && !STRIDED && !FUSE), "the residual epilogue is the eval-mode conv3 form");
   constexpr int PIX = 2 * K + 32;
   constexpr int KS = K / 32;
   constexpr int CH8 = K / 8;                  // 16-byte chunks per row
@@ -479,6 +482,29 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
     }
   };
 
+  // RES: the identity pieces of a stage in the ACCUMULATOR layout (this lane's 4 NTW channels of row i * 16 + r16), requested D stages
+  // ahead into register set (stage % D) -- right after that set's previous use, unconditional, rows past the end clamped
+  constexpr int NCQ = RES ? NTW : 1;                 // dwordx2 pieces per tile (4 channels each)
+  u32x2 rq[RES ? D : 1][RES ? TMS : 1][NCQ];
+  auto qload = [&](u32x2 (&q)[RES ? TMS : 1][NCQ], int stage) {
+    if constexpr (RES) {
+      const int cbq = ((slice * 4 + wid) * NTW) * 16 + 4 * NTW * q4;
+#pragma unroll
+      for (int i = 0; i < TMS; ++i) {
+        int m = gs(stage) * SM + i * 16 + r16;
+        m = (m < a.M && stage < a.spb) ? m : a.M - 1;
+        const bf16_t* src = a.idn + (size_t)m * a.N + cbq;
+        if constexpr (NTW == 1) q[i][0] = *reinterpret_cast<const u32x2*>(src);
+        else {
+#pragma unroll
+          for (int h = 0; h < NTW / 2; ++h) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(src + 8 * h);
+            q[i][2 * h] = u32x2{t[0], t[1]}; q[i][2 * h + 1] = u32x2{t[2], t[3]};
+          }
+        }
+      }
+    }
+  };
   gload(ra[0], rok[0], s_begin, rb[0]);
   if (xf) {   // producer's BatchNorm coefficients (replicated statistics summed here), while the first rows are in flight
     float* coef = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
@@ -509,6 +535,10 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
 #pragma unroll
   for (int j = 1; j <= D; ++j)                       // stage s_begin + j waits in register set j % D (always issued: counted waits)
     gload(ra[j % D], rok[j % D], s_begin + j, rb[FUSE ? j % D : 0]);
+  if constexpr (RES) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) qload(rq[j], s_begin + j);
+  }
   __syncthreads();
 
   constexpr int NC = 4 * NTW;
@@ -564,6 +594,13 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
         if constexpr (AFFINE) {
 #pragma unroll
           for (int c = 0; c < NC; ++c) v[c] = v[c] * scv[c] + shv[c];
+          if constexpr (RES) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+              v[4 * j] += __uint_as_float(rq[u][i][j][0] << 16); v[4 * j + 1] += __uint_as_float(rq[u][i][j][0] & 0xffff0000u);
+              v[4 * j + 2] += __uint_as_float(rq[u][i][j][1] << 16); v[4 * j + 3] += __uint_as_float(rq[u][i][j][1] & 0xffff0000u);
+            }
+          }
           if (a.relu) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -586,6 +623,7 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
     // next stage: its register set -> the other ring half, then that set requests stage s + 1 + D
     lstore(ra[(u + 1) % D], rok[(u + 1) % D], buf ^ 1, s + 1, rb[FUSE ? (u + 1) % D : 0]);
     gload(ra[(u + 1) % D], rok[(u + 1) % D], s + 1 + D, rb[FUSE ? (u + 1) % D : 0]);
+    if constexpr (RES) qload(rq[u], s + D);
     __syncthreads();
     }
    }
@@ -787,10 +825,16 @@ struct AsArgs {
   int M, N, nq;                  // nq: channel parts (workgroups per row block)
   int Hin, Win, Ho, Wo, stride;  // STRIDED: output row (b, ho, wo) reads input pixel (b, ho * stride, wo * stride)
   unsigned long long* stamps;   // debug (tools/as_stamps.py), normally NULL
+  const bf16_t* res;            // RES: [M][N] residual (the block's identity), added after scale / shift, before the ReLU
 };
 
-template <int K, int NCH, bool AFFINE, bool STRIDED>
+// RES (eval mode, conv3 of a Bottleneck: out = relu(bn3(conv3(x)) + identity) with bn3 folded to scale / shift): the identity's 16-byte
+// piece of tile i of chunk c is REQUESTED in K-step i of chunk c and consumed in K-step i of chunk c + 1 (where chunk c's epilogue
+// runs), i.e. a full chunk (KS K-steps, 2 KS filter loads) ahead: unconditional, clamped rows -- the counted waits of the filter ring
+// stay counted.  No statistics in this form.
+template <int K, int NCH, bool AFFINE, bool STRIDED, bool RES = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_astat_kernel(AsArgs a) {
+  static_assert(!RES || (AFFINE && !STRIDED), "the residual epilogue is the eval-mode conv3 form");
   // NCH chunks of 128 output channels (32 per wave, NTW = 2).  TWO accumulator sets alternate by chunk: the epilogue of chunk c-1
   // (accumulator reads, statistics, bf16 packing, stores: ~600 VALU instructions) is spread over the K-steps of chunk c, one
   // 16-row tile per K-step, so it runs under that chunk's MFMAs instead of between two MFMA blocks (measured before: 3.5 us per
@@ -891,13 +935,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   f32x4 accA[TM][NTW], accB[TM][NTW];
   float es[NC], ess[NC];
+  u32x4 rres[RES ? TM : 1];                                           // RES: the identity pieces of the chunk whose epilogue comes next
+  // rows of this lane's accumulator tiles, clamped (rows past M re-read row M - 1: loads stay unconditional)
+  auto res_request = [&](int ch, int i) {
+    if constexpr (RES) {
+      const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;
+      int m = bm * BM + i * 16 + r16;
+      m = m < a.M ? m : a.M - 1;
+      rres[i] = *reinterpret_cast<const u32x4*>(a.res + (size_t)m * a.N + ch0 * CW + cb);
+    }
+  };
   // tile i of chunk `ch` from accumulator set `acc`: statistics partials, (eval: scale / shift / ReLU), bf16, one 16-byte store
   auto tile_epilogue = [&](f32x4 (&acc)[TM][NTW], int ch, int i) {
     const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;             // this lane's 8 consecutive channels (inside the workgroup's part)
     const int m = bm * BM + i * 16 + r16;
-    if (i == 0) {
+    if constexpr (!RES) {
+      if (i == 0) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; }
+        for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; }
+      }
     }
     if (m < a.M) {
       float v[NC];
@@ -905,14 +961,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
+      if constexpr (!RES) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
+        for (int c = 0; c < NC; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
+      }
       if constexpr (AFFINE) {
 #pragma unroll
         for (int c = 0; c < NC; c += 4) {
           const f32x4 s4 = *reinterpret_cast<const f32x4*>(aff + cb + c), h4 = *reinterpret_cast<const f32x4*>(aff + CW * NCH + cb + c);
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[c + q] = v[c + q] * s4[q] + h4[q];
+        }
+        if constexpr (RES) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            v[2 * d] += __uint_as_float(rres[i][d] << 16);
+            v[2 * d + 1] += __uint_as_float(rres[i][d] & 0xffff0000u);
+          }
         }
         if (a.relu) {
 #pragma unroll
@@ -924,6 +989,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   };
   auto stats_park = [&](int ch) {                                    // per-channel sums of chunk `ch` -> LDS (flushed once at the end)
+    if constexpr (RES) return;
     if (a.stats) {
       const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;
 #pragma unroll
@@ -963,6 +1029,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (ks < TM) tile_epilogue(prev, ch - 1, ks);
         else if (ks == TM) stats_park(ch - 1);
       }
+      if (ks < TM) res_request(ch, ks);                             // RES: this chunk's identity piece for tile ks (its register is free now)
       __builtin_amdgcn_sched_barrier(0);
     }
     if (ch == 0) AS_STAMP(2);
@@ -975,7 +1042,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     stats_park(NCH - 1);
   }
   AS_STAMP(4);
-  if (a.stats) {
+  if (!RES && a.stats) {
     float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);
     __syncthreads();
     for (int t = tid; t < 2 * CW * NCH; t += 256)                  // sstat = [sum | sumsq] of this part's CW NCH channels
@@ -1275,7 +1342,7 @@ inline bool pw_cfg(int K, int N, PwCfg* c) {
   return false;
 }
 
-template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE, bool FUSE = false>
+template <int K, int NTW, int TMS, int D, bool STRIDED, bool AFFINE, bool FUSE = false, bool RES = false>
 int launch_pw___(PwArgs& a, hipStream_t st, double flops, bool xf) {
   constexpr int SM = 16 * TMS, PIX = 2 * K + 32;
   const int lds = 2 * SM * PIX + (xf ? (FUSE ? 4 : 2) * K * (int)sizeof(float) : 0);
@@ -1287,14 +1354,14 @@ int launch_pw___(PwArgs& a, hipStream_t st, double flops, bool xf) {
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev] && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
   // workgroups that are resident together (registers AND LDS: the fused loader's two register sets leave 2 per CU where the LDS
   // alone would take 3 -- a grid sized for 3 ran as one full round plus a 36 % one); the row range is cut into that many pieces
   if (!occ_dev[dev]) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE>), 256, 160 * 1024 / 3) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE, RES>), 256, 160 * 1024 / 3) != hipSuccess || nb < 1) nb = 1;
     occ_dev[dev] = nb;
   }
   int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ > occ_dev[dev]) occ = occ_dev[dev]; if (occ < 1) occ = 1;
@@ -1304,13 +1371,14 @@ int launch_pw___(PwArgs& a, hipStream_t st, double flops, bool xf) {
   static const bool interleave = [] { const char* e = getenv("ST_PW_INTERLEAVE"); return !e || atoi(e) != 0; }();   // A/B switch
   a.mbs = interleave ? mbs : 0;
   StProfScope prof(K == 64 ? 12 : K == 128 ? 13 : K == 256 ? 14 : 15, flops, st);
-  hipLaunchKernelGGL((conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE>), dim3(mbs * a.nbn), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_wreg_kernel<K, NTW, TMS, D, STRIDED, AFFINE, FUSE, RES>), dim3(mbs * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
 }
 template <int K, int NTW, int TMS, int D, bool STRIDED>
 int launch_pw__(PwArgs& a, hipStream_t st, double flops, bool xf) {
+  if constexpr (!STRIDED) { if (a.idn) return launch_pw___<K, NTW, TMS, D, false, true, false, true>(a, st, flops, xf); }
   return a.scale ? launch_pw___<K, NTW, TMS, D, STRIDED, true>(a, st, flops, xf) : launch_pw___<K, NTW, TMS, D, STRIDED, false>(a, st, flops, xf);
 }
 
@@ -1341,7 +1409,7 @@ extern "C" int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream) {
   ST_CHECK(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->stride >= 1, "st_conv1x1_wreg: bad geometry");
   ST_CHECK((d->scale == nullptr) == (d->shift == nullptr), "st_conv1x1_wreg: scale and shift go together");
   ST_CHECK(d->scale || !d->relu, "st_conv1x1_wreg: relu comes with the eval-mode scale / shift epilogue");
-  ST_CHECK(!d->residual, "st_conv1x1_wreg: no residual input (a load in the epilogue would drain the row prefetch): use st_conv");
+  ST_CHECK(!d->residual || (d->scale && d->stride == 1 && d->y && !d->stats), "st_conv1x1_wreg: the residual epilogue is the eval-mode form (scale / shift given, stride 1, no statistics)");
   ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f), "st_conv1x1_wreg: input transform needs gamma, beta, count");
   ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->in_stats_replicas >= 0 && d->in_stats_replicas <= 1024, "st_conv1x1_wreg: bad stats_replicas");
   PwArgs a{};
@@ -1350,6 +1418,7 @@ extern "C" int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream) {
   a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_count = d->in_count; a.in_eps = d->in_eps;
   a.in_srep = d->in_stats_replicas > 1 ? d->in_stats_replicas : 1;
   a.Hin = d->Hin; a.Win = d->Win; a.stride = d->stride;
+  a.idn = reinterpret_cast<const bf16_t*>(d->residual);
   a.Ho = (d->Hin - 1) / d->stride + 1; a.Wo = (d->Win - 1) / d->stride + 1;
   const long M = (long)d->B * a.Ho * a.Wo;
   ST_CHECK(M * (d->C > d->N ? d->C : d->N) < (1L << 40) && M < (1L << 31) - 4096, "st_conv1x1_wreg: too many rows");
@@ -1392,7 +1461,7 @@ int launch_ks(KsArgs& a, hipStream_t st, double flops) {
 }  // namespace
 
 namespace {
-template <int K, int NCH, bool AFFINE, bool STRIDED>
+template <int K, int NCH, bool AFFINE, bool STRIDED, bool RES = false>
 int launch_as__(AsArgs& a, hipStream_t st, double flops) {
   constexpr int lds = 112 * (2 * K + 32) + 2 * 128 * NCH * 4 + 2 * K * 4 + (AFFINE ? 2 * 128 * NCH * 4 : 0);
   static_assert(lds <= 160 * 1024, "activation block does not fit");
@@ -1400,17 +1469,18 @@ int launch_as__(AsArgs& a, hipStream_t st, double flops) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
   StProfScope prof(K == 256 ? 18 : 19, flops, st);
-  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED>), dim3(((a.M + 111) / 112) * a.nq), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED, RES>), dim3(((a.M + 111) / 112) * a.nq), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
 }
 template <int K, int NCH, bool STRIDED>
 int launch_as_(AsArgs& a, hipStream_t st, double flops) {
+  if constexpr (!STRIDED) { if (a.res) return launch_as__<K, NCH, true, false, true>(a, st, flops); }
   return a.scale ? launch_as__<K, NCH, true, STRIDED>(a, st, flops) : launch_as__<K, NCH, false, STRIDED>(a, st, flops);
 }
 }  // namespace
@@ -1428,7 +1498,7 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   ST_CHECK(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->stride >= 1, "st_conv1x1_astat: bad geometry");
   ST_CHECK(strided == (d->N == 2 * d->C), "st_conv1x1_astat: C=%d N=%d comes with stride %s", d->C, d->N, d->N == 2 * d->C ? "> 1" : "1");
   ST_CHECK((d->scale == nullptr) == (d->shift == nullptr) && (d->scale || !d->relu), "st_conv1x1_astat: scale, shift (and relu) go together");
-  ST_CHECK(!d->residual, "st_conv1x1_astat: no residual input (use st_conv)");
+  ST_CHECK(!d->residual || (d->scale && !strided && !d->stats), "st_conv1x1_astat: the residual epilogue is the eval-mode form (scale / shift given, stride 1, no statistics)");
   ST_CHECK(!d->in_stats || (d->in_gamma && d->in_beta && d->in_count > 0.f), "st_conv1x1_astat: input transform needs gamma, beta, count");
   ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->in_stats_replicas >= 0 && d->in_stats_replicas <= 1024, "st_conv1x1_astat: bad stats_replicas");
   AsArgs a;
@@ -1441,6 +1511,7 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   const long M = (long)d->B * a.Ho * a.Wo;
   ST_CHECK(M < (1L << 31) - 4096, "st_conv1x1_astat: too many rows");
   a.M = (int)M; a.N = d->N; a.stamps = st_debug_stamps_ptr();
+  a.res = reinterpret_cast<const bf16_t*>(d->residual);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)M * d->N * d->C;
   a.nq = 1;

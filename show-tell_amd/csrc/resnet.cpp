@@ -46,6 +46,9 @@ struct st_resnet {
   // for st_resnet_update_running -- lets concurrent forwards on different streams apply their momentum updates in order
   mutable std::map<const void*, PendingUpdate> pending;
   mutable std::mutex mu;
+  // test / diagnosis aid (st_resnet_set_taps): when set, every forward copies each residual block's OUTPUT ([B][h][w][C], compute
+  // dtype) into this buffer, block after block -- the block-by-block parity test feeds them to the oracle one block at a time
+  void* taps = nullptr; size_t taps_bytes = 0;
 };
 
 namespace {
@@ -201,7 +204,26 @@ extern "C" int st_resnet_conv_info(const st_resnet* r, int i, int* cin, int* cou
   return 0;
 }
 
+extern "C" int st_resnet_set_taps(st_resnet* r, void* buf, size_t bytes) {
+  ST_CHECK(r && (buf || bytes == 0), "st_resnet_set_taps: null pointer");
+  std::lock_guard<std::mutex> lk(r->mu);
+  r->taps = buf; r->taps_bytes = buf ? bytes : 0;
+  return 0;
+}
+
 namespace {
+// ST_LAYER_LOG=<file>: one line per kernel launch of a forward, in launch order -- which kernel family took which layer, its
+// geometry, algorithmic FLOPs and HBM bytes (tools/layer_table.py joins it with the rocprofv3 kernel trace of the same process)
+FILE* layer_log() {
+  static FILE* f = [] { const char* e = getenv("ST_LAYER_LOG"); return e && *e ? fopen(e, "w") : nullptr; }();
+  return f;
+}
+void log_launch(const char* kernel, const char* what, int cin, int cout, int k, int stride, int hin, int win, double flops, double bytes) {
+  if (FILE* f = layer_log()) {
+    fprintf(f, "%s,%s,%d,%d,%d,%d,%d,%d,%.0f,%.0f\n", kernel, what, cin, cout, k, stride, hin, win, flops, bytes);
+    fflush(f);
+  }
+}
 struct Plan {
   size_t in_bytes, s2dw_bytes, stem_bytes, wide_bytes, narrow_bytes, stats_bytes, fold_bytes, total;
 };
@@ -325,7 +347,9 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     }
     *ho = d.Ho; *wo = d.Wo;
     tab.count[ci] = (float)((long)B * d.Ho * d.Wo);
-    if (c.ntw > 0 && c.k == 1 && use_img && !d.residual) {
+    // (eval mode: conv3 takes the block's identity in its epilogue -- the register-filter and activation-stationary kernels have that
+    // form for stride 1 and <= 512 input channels, i.e. every conv3 of a Bottleneck)
+    if (c.ntw > 0 && c.k == 1 && use_img && (!d.residual || (c.stride == 1 && c.cin <= 512))) {
       // pointwise, filter slice in registers (conv_img.hip): producer's BatchNorm + ReLU in the row loader, replicated statistics
       st_conv1x1_wreg_desc g;
       memset(&g, 0, sizeof(g));
@@ -333,7 +357,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       g.B = B; g.Hin = hin; g.Win = win; g.C = c.cin; g.N = c.cout; g.stride = c.stride;
       g.in_stats = d.in_stats; g.in_gamma = d.in_gamma; g.in_beta = d.in_beta; g.in_count = d.in_count; g.in_eps = d.in_eps;
       g.in_stats_replicas = in_ci >= 0 ? tab.rep[in_ci] : 0;
-      g.scale = d.scale; g.shift = d.shift; g.relu = d.relu;
+      g.scale = d.scale; g.shift = d.shift; g.relu = d.relu; g.residual = d.residual;
       if (train) {
         // four replicas: the statistics leave a workgroup as full-wave atomics over consecutive channels (block_stats_flush), so the
         // same-address queue is what is left to spread -- and every consumer adds the replicas up in its prologue (cheap at 4)
@@ -358,6 +382,8 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         }
         k.count = tab.count[fz->ci]; k.eps = eps; k.rows = (long)B * hin * win; k.C1 = pc.cin; k.C2 = c.cin; k.N = c.cout;
         if (st_conv_b2b(&k, stream)) return 1;
+        log_launch("conv_b2b", "conv3 recomputed + bn3 + identity + relu + next conv1", pc.cin, c.cout, 1, 1, hin, win,
+                   2.0 * k.rows * ((double)pc.cin * pc.cout + (double)c.cin * c.cout), (double)k.rows * (pc.cin + 2.0 * pc.cout + c.cout) * es);
       } else if (fz) {
         const ConvL& pc = r->convs[fz->ci];
         st_conv1x1_kfuse_desc k;
@@ -373,12 +399,24 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
           k.id_stats_replicas = tab.rep[fz->res_ci];
         }
         if (st_conv1x1_kfuse(&k, stream)) return 1;
-      } else if (use_astat(c)) {
-        if (st_conv1x1_astat(&g, stream)) return 1;
-      } else if (c.cin > 512) {
-        ST_CHECK(!g.in_stats, "st_resnet_forward: the long-K pointwise kernel has no input transform");
-        if (st_conv1x1_kstream(&g, stream)) return 1;
-      } else if (st_conv1x1_wreg(&g, stream)) return 1;
+        log_launch("conv1x1_wreg", "block end (bn3 + identity + relu) fused into conv1", c.cin, c.cout, 1, 1, hin, win,
+                   2.0 * k.rows * (double)c.cin * c.cout, (double)k.rows * (3.0 * c.cin + c.cout) * es);
+      } else {
+        const double rows_o = (double)B * d.Ho * d.Wo;
+        const double fl = 2.0 * rows_o * c.cin * c.cout;
+        const double by = (rows_o * c.cin + (double)c.cin * c.cout + (y ? rows_o * c.cout * (g.residual ? 2.0 : 1.0) : 0.0)) * es;
+        if (use_astat(c)) {
+          if (st_conv1x1_astat(&g, stream)) return 1;
+          log_launch("conv1x1_astat", "1x1", c.cin, c.cout, 1, c.stride, hin, win, fl, by);
+        } else if (c.cin > 512) {
+          ST_CHECK(!g.in_stats, "st_resnet_forward: the long-K pointwise kernel has no input transform");
+          if (st_conv1x1_kstream(&g, stream)) return 1;
+          log_launch("conv1x1_kstream", "1x1", c.cin, c.cout, 1, c.stride, hin, win, fl, by);
+        } else {
+          if (st_conv1x1_wreg(&g, stream)) return 1;
+          log_launch("conv1x1_wreg", y ? "1x1" : "1x1 statistics only", c.cin, c.cout, 1, c.stride, hin, win, fl, by);
+        }
+      }
     } else if (c.ntw > 0 && c.k == 3 && use_img && !d.residual && st_conv3x3_img_supported(hin, win, c.cin, c.cout) == c.ntw) {
       // image-resident 3x3 (conv_img.hip): the producer's BatchNorm + ReLU ride in its fill, replicated statistics in and out
       st_conv3x3_img_desc g;
@@ -397,13 +435,21 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
       }
       if (st_conv3x3_img(&g, stream)) return 1;
-    } else if (st_conv(&d, stream)) return 1;
+      log_launch("conv3x3_img", "3x3", c.cin, c.cout, 3, 1, hin, win, 2.0 * B * hin * win * 9.0 * c.cin * c.cout,
+                 ((double)B * hin * win * (c.cin + c.cout) + 9.0 * c.cin * c.cout) * es);
+    } else {
+      if (st_conv(&d, stream)) return 1;
+      const double rows_o = (double)B * d.Ho * d.Wo;
+      log_launch("igemm", d.residual ? "conv + residual (eval)" : "conv", c.cin, c.cout, c.k, c.stride, hin, win, 2.0 * rows_o * c.k * c.k * c.cin * c.cout,
+                 ((double)B * hin * win * cin_p + (double)c.k * c.k * cin_p * c.cout + rows_o * c.cout * (d.residual ? 2.0 : 1.0)) * es);
+    }
     // every consumer of a layer's statistics sums up to 16 replicas itself (bn_act's register-coefficient kernel, the
     // conv_img.hip loaders, the running-buffer update); only st_conv's input transform and the stem's pool read replica 0
     if (train && tab.rep[ci] > 1 && !(keep_rep && tab.rep[ci] <= 16)) {
       const int c2 = 2 * c.cout;
       hipLaunchKernelGGL(bn_reduce_replicas_kernel, dim3((c2 + 255) / 256), dim3(256), 0, st, stats + tab.soff[ci], tab.rep[ci], c2);
       ST_LAUNCH_CHECK();
+      log_launch("bn_reduce_replicas", "statistics replicas -> replica 0", c.cout, c.cout, 0, 0, 0, 0, 0.0, 0.0);
       tab.rep[ci] = 1;   // consumers (bn_act, running-buffer update) read replica 0
     }
     return 0;
@@ -420,7 +466,9 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       d.res_bn = 1; d.res_stats = stats + tab.soff[res_ci]; d.res_stats_replicas = tab.rep[res_ci]; d.res_gamma = bn_gamma + rc.bnoff; d.res_beta = bn_beta + rc.bnoff;
     }
     d.dtype = dt; d.rows = rows; d.C = c.cout; d.count = (float)rows; d.eps = eps; d.relu = relu;
-    return st_bn_act(&d, stream);
+    if (st_bn_act(&d, stream)) return 1;
+    log_launch("bn_act", res ? "bn + identity + relu" : "bn + relu", c.cout, c.cout, 0, 0, 0, 0, 0.0, (double)rows * c.cout * (res ? 3.0 : 2.0) * es);
+    return 0;
   };
 
   int h, w;
@@ -450,6 +498,8 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       sd.scale = fscale + c0.bnoff; sd.shift = fshift + c0.bnoff;
     }
     if (st_stem_conv_pool(&sd, stream)) return 1;
+    log_launch("stem_pool", "7x7/2 conv + statistics + 3x3/2 pool", 3, 64, 7, 2, H, W, 2.0 * B * h * w * 147.0 * 64,
+               (double)B * (H / 2 + 3) * (W / 2 + 3) * 16 * es + (double)B * conv_out(h, 3, 2, 1) * conv_out(w, 3, 2, 1) * 64 * es);
   } else {
     if (conv(0, in8, H, W, stem, nullptr, 1, &h, &w, -1, false)) return 1;
     if (train) {   // bn1 + relu folded into the pool: the 64-channel 112x112 map is read once instead of three times
@@ -461,6 +511,15 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
   const int stem_in = (stem_fused && train) ? 0 : -1;   // the first block's conv1 / downsample read relu(bn1(.)) of wide[0] in their loaders
   int cur = 0;  // wide[cur] holds the block input
+  size_t taps_used = 0;
+  auto tap = [&](const void* src, int hh, int ww, int C) -> int {     // st_resnet_set_taps: block outputs, one after the other
+    if (!r->taps) return 0;
+    const size_t nb = (size_t)B * hh * ww * C * es;
+    ST_CHECK(taps_used + nb <= r->taps_bytes, "st_resnet_forward: taps buffer too small (%zu needed so far, %zu given)", taps_used + nb, r->taps_bytes);
+    if (hipMemcpyAsync(reinterpret_cast<char*>(r->taps) + taps_used, src, nb, hipMemcpyDeviceToDevice, st) != hipSuccess) { st_set_error("st_resnet_forward: tap copy failed"); return 1; }
+    taps_used += nb;
+    return 0;
+  };
 
   // Train, 256-channel block inputs (layer1 and the first block of layer2): the block-end pass relu(bn3(raw) + identity) is formed by
   // the NEXT block's conv1 loader (st_conv1x1_kfuse) -- that pass and conv1 are both HBM time there and the fusion drops one full read
@@ -495,6 +554,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       static const bool xf_env = [] { const char* e = getenv("ST_CONV2_XF"); return !e || atoi(e) != 0; }();
       const bool fuse1x = xf_env && train && use_img && !fuse1 && c2.k == 3 && c2.cin % 64 == 0;
       if (conv(b.c1, c1_in, h, w, narrow[0], nullptr, 1, &h1, &w1, bi == 0 ? stem_in : -1, !fuse1x, fz)) return 1;
+      if (fz && tap(xin, h, w, r->convs[b.c1].cin)) return 1;      // the PREVIOUS block's output was formed by this conv1's loader
       if (train && !fuse1 && !fuse1x && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       const bool fuse2_ = train && c3.cin % 64 == 0;              // conv3 applies bn2 + relu in its loader
       if (conv(b.c2, narrow[0], h1, w1, narrow[1], nullptr, 1, &h2, &w2, (fuse1 || fuse1x) ? b.c1 : -1, c3_sums || !fuse2_)) return 1;
@@ -514,14 +574,16 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         defer = n1.k == 1 && n1.stride == 1 && n1.cin == 256 && n1.ntw > 0 && !use_astat(n1) && c3.cout == n1.cin &&
                 st_conv1x1_kfuse_supported(n1.cin, n1.cout) == n1.ntw;
         // the 56 x 56 boundaries: conv3 (64 -> 256) is recomputed inside the fused kernel (st_conv_b2b) and runs here for its statistics only
-        b2b = defer && b2b_env && fuse2 && c3.k == 1 && c3.stride == 1 && c3.ntw > 0 && !use_astat(c3) &&
+        // conv_b2b_kernel indexes the fragment-major filters with FIXED tile permutations: conv3 packed with ntw = 2, the next conv1
+        // with ntw = N / 64 (conv_b2b.hip:63-65); a retuned pw_cfg table / ST_PW_CFG that packs another ntw must not reach it
+        b2b = defer && b2b_env && fuse2 && c3.k == 1 && c3.stride == 1 && c3.ntw == 2 && !use_astat(c3) &&
               c3.ntw == st_conv1x1_wreg_supported(c3.cin, c3.cout) && n1.ntw == st_conv1x1_wreg_supported(n1.cin, n1.cout) &&
-              st_conv_b2b_supported(c3.cin, c3.cout, n1.cout);
+              n1.ntw == n1.cout / 64 && st_conv_b2b_supported(c3.cin, c3.cout, n1.cout);
       }
       // the 28 x 28 blocks (conv3 128 -> 512): the same recomputation, stopping at the block output -- conv3 runs for its statistics,
       // st_conv_b2b (N = 0) forms x = relu(bn3(conv3(..)) + identity) from the narrow tensor: the raw 512-channel tensor (103 MB at
       // B = 128) is neither written nor read
-      const bool lite = !defer && train && use_img && b2b_env && fuse2 && c3.k == 1 && c3.stride == 1 && c3.ntw > 0 && !use_astat(c3) &&
+      const bool lite = !defer && train && use_img && b2b_env && fuse2 && c3.k == 1 && c3.stride == 1 && c3.ntw == 2 && !use_astat(c3) &&
                         c3.ntw == st_conv1x1_wreg_supported(c3.cin, c3.cout) && st_conv_b2b_supported(c3.cin, c3.cout, 0);
       if (conv(b.c3, narrow[1], h2, w2, (b2b || lite) ? nullptr : wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
       if (defer) pend = Pending{true, b.c3, res, b.ds, oth, b.ds >= 0 ? dsb : cur, b2b, narrow[1], b.c2};
@@ -556,6 +618,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       if (train && bnact(b.c2, wide[oth], (long)B * h3 * w3, 1, res, b.ds)) return 1;
     }
     h = h3; w = w3; cur = oth;
+    if (!pend.on && tap(wide[cur], h, w, r->bottleneck ? r->convs[b.c3].cout : r->convs[b.c2].cout)) return 1;
   }
 
   const size_t feat_bytes = (size_t)B * h * w * r->feat_dim * es;

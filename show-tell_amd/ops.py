@@ -338,15 +338,15 @@ def conv1x1_astat_supported(Cin, N):
     return int(lib().st_conv1x1_astat_supported(Cin, N))
 
 
-def conv1x1_astat(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, in_bn=None, out=None):
+def conv1x1_astat(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, in_bn=None, out=None, residual=None):
     """Activation-stationary 1x1 conv (st_conv1x1_astat): stride 1 with (C, N) in {(256, 1024), (512, 2048)}, stride 2 with (256, 512) /
     (512, 1024); w_frag = pack_conv_weight_frag(w, conv1x1_astat_supported(C, N))."""
-    _dev(x, w_frag, stats, scale, shift, out)
+    _dev(x, w_frag, stats, scale, shift, out, residual)
     B, H, W, Cc = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if out is None:
         out = torch.empty(B, Ho, Wo, N, device=x.device, dtype=torch.bfloat16)
-    d = Conv1x1WregDesc(_p(x), _p(w_frag), _p(out), None, _p(stats), int(stats_replicas), _p(scale), _p(shift), int(relu),
+    d = Conv1x1WregDesc(_p(x), _p(w_frag), _p(out), _p(residual), _p(stats), int(stats_replicas), _p(scale), _p(shift), int(relu),
                         None, None, None, 0.0, 0.0, 0, B, H, W, Cc, N, int(stride))
     if in_bn is not None:
         _dev(in_bn["stats"], in_bn["gamma"], in_bn["beta"])

@@ -37,6 +37,11 @@ if __name__ == "__main__":
     dist.init_process_group(backend="gloo", rank=rank, world_size=2)
     from showtell_amd.train import Trainer
     cnn, rnn, opt = build(seed=50 + rank)              # different initial weights per rank: the broadcast must equalise them
+    probe = torch.randn(2, 3, SIZE, SIZE, generator=torch.Generator().manual_seed(9)).cuda()
+    cnn.eval()
+    with torch.no_grad():
+        cnn.backbone_features(probe)                   # a forward BEFORE Trainer(): the backbone packs THIS rank's own filters (its cache
+    cnn.train()                                        # is keyed on tensor versions; the broadcast below must invalidate it)
     tr = Trainer(cnn, rnn, opt, world_size=2)
     losses = []
     for img, cap, lens in batches(rank):
@@ -48,6 +53,12 @@ if __name__ == "__main__":
     both = [None, None]
     dist.all_gather_object(both, flat)
     assert np.array_equal(both[0], both[1]), "ranks ended with different parameters"
+    with torch.no_grad():
+        pf = cnn.backbone_features(probe).detach().cpu().numpy()   # train-mode BN: a function of the frozen filters / gamma / beta only
+    feats = [None, None]
+    dist.all_gather_object(feats, pf)
+    # (float atomics sum the batch statistics in a different order per process: equal to fp32 rounding, not bit for bit)
+    assert np.allclose(feats[0], feats[1], rtol=1e-3, atol=1e-4 * float(np.abs(feats[0]).max())), "the frozen backbones of the two ranks differ: a rank kept its pre-broadcast packed filters"
     if rank == 0:
         np.savez(out, flat=flat, losses=np.array(losses), rm=cnn.last_layer.running_mean.detach().cpu().numpy())
     dist.barrier()

@@ -63,6 +63,42 @@ def test_beam_search_full_size_matches_oracle_and_is_batch_invariant():
     assert [h[0][0] if h else None for h in sub] == [h[0][0] if h else None for h in got[3:7]]
 
 
+def test_beam_search_256_images_beam5_config5_size():
+    """BASELINE configs[4] at its real size: 256 images x beam 5 = 1280-row cells (the `MT` tall-cell path that shares weight
+    fragments across row tiles) and st_beam_select over 256 image slots.  fp32 kernels: (i) the first 12 images of the 256-image
+    search equal the 12-image search of the test above image by image (batch invariance across the cell-size change), (ii) eight
+    images spread over the batch equal the CPU oracle (beam_search.py:45-97 restated), (iii) every non-empty hypothesis starts
+    with <start>, ends with <end> and is at most max_length long."""
+    E, H, V, L, B = 512, 512, 10000, 5, 256
+    params = R.init_decoder_params(E, H, V, L, "gru", seed=6)
+    params["linear.weight"] = params["linear.weight"] * 12.0
+    params["linear.bias"][2] += 1.5
+    m = _make("gru", params, torch.float32).eval()
+    g = torch.Generator().manual_seed(6)
+    feat12 = torch.randn(12, E, generator=g)                       # the same 12 images as the test above
+    feat = torch.cat([feat12, torch.randn(B - 12, E, generator=g)], 0)
+    got = m.beam_search(feat.cuda(), beam_width=5, num_hypotheses=1, max_length=25)
+    assert len(got) == B
+    small = m.beam_search(feat12.cuda(), beam_width=5, num_hypotheses=1, max_length=25)
+    assert [h[0][0] if h else None for h in small] == [h[0][0] if h else None for h in got[:12]]
+    for a_, b_ in zip(small, got[:12]):
+        if a_:
+            assert abs(a_[0][1] - b_[0][1]) < 1e-3
+    checked = 0
+    for b in (0, 5, 40, 97, 128, 191, 230, 255):
+        with torch.no_grad():
+            init, gen = R.gru_beam_callbacks(params, feat[b])
+            hyp = R.beam_search(init, gen, [0], 1, 2, beam_width=5, num_hypotheses=1, max_length=25)
+        assert len(got[b]) == len(hyp), b
+        if hyp:
+            checked += 1
+            assert got[b][0][0] == hyp[0].to_sequence_of_values(), b
+    assert checked >= 2
+    done = [h[0][0] for h in got if h]
+    assert len(done) >= B // 8
+    assert all(s_[0] == 1 and s_[-1] == 2 and len(s_) <= 26 for s_ in done)
+
+
 def test_bf16_greedy_bleu4_vs_fp32_oracle():
     """BASELINE config 5 quality gate at the full decoder shape: 25-token greedy captions of the bf16 kernels against the fp32
     CPU oracle (rnn.py:37-58) on the same weights, scored with the reference's BLEU (corpus BLEU-4 >= 0.9: random-init

@@ -164,7 +164,7 @@ def test_conv1x1_wreg_matches_conv2d_and_igemm(case):
     np.testing.assert_allclose(tot, s0.cpu().numpy(), rtol=1e-4, atol=1e-3 * scale * np.sqrt(r2.shape[0]))
 
 
-@pytest.mark.parametrize("case", [PW_CASES[0], PW_CASES[1], PW_CASES[4], PW_CASES[5], PW_CASES[8]])
+@pytest.mark.parametrize("case", [PW_CASES[0], PW_CASES[1], PW_CASES[4], PW_CASES[5], PW_CASES[8], PW_CASES[9]])
 def test_conv1x1_wreg_fused_input_bn_relu_and_eval_epilogue(case):
     ops = _ops()
     B, H, W, C, N, s = case
@@ -189,7 +189,17 @@ def test_conv1x1_wreg_fused_input_bn_relu_and_eval_epilogue(case):
     assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
     from showtell_amd import ShowTellHipError
     with pytest.raises(ShowTellHipError):
-        ops.conv1x1_wreg(xd, wf, N, stride=s, residual=y)
+        ops.conv1x1_wreg(xd, wf, N, stride=s, residual=y)        # the residual form needs the eval-mode scale / shift
+    # eval-mode conv3 of a Bottleneck (stride 1): relu(conv * scale + shift + identity), the identity requested D stages ahead
+    conv = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, s, 0).permute(0, 2, 3, 1)
+    idn = (torch.randn(conv.shape, generator=g) * conv.abs().mean().item() * 2).bfloat16()
+    for relu in (True, False):
+        y3 = ops.conv1x1_wreg(xd, wf, N, stride=s, scale=sc.cuda(), shift=sh.cuda(), relu=relu, residual=idn.cuda())
+        ref3 = conv * sc + sh + idn.float()
+        ref3 = F.relu(ref3) if relu else ref3
+        assert (y3.float().cpu() - ref3).abs().max().item() <= 1.5e-2 * ref3.abs().max().item()
+    y0r = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16), 1, 1, s, 0, scale=sc.cuda(), shift=sh.cuda(), relu=False, residual=idn.cuda())
+    assert (y3.float() - y0r.float()).abs().max().item() <= 2.0 ** -7 * ref3.abs().max().item()
 
 
 # ---- st_conv1x1_kstream: (B, H, W, C, N, stride) ---------------------------------------------------------------------
@@ -278,6 +288,20 @@ def test_conv1x1_astat_matches_conv2d_igemm_and_separate_bn_pass(case):
     y2 = ops.conv1x1_astat(xd, wf, N, stride=S, scale=sc.cuda(), shift=sh.cuda(), relu=True)
     ref2 = F.relu(ref * sc + sh)
     assert (y2.float().cpu() - ref2).abs().max().item() <= 1.5e-2 * ref2.abs().max().item()
+    if S == 1:
+        # eval-mode conv3 of a Bottleneck: relu(conv * scale + shift + identity) in the epilogue (the identity requested a chunk ahead),
+        # against fp32 and against the implicit-GEMM kernel's residual epilogue (same arithmetic order: fma, add, max)
+        idn = (torch.randn(ref.shape, generator=g) * ref.abs().mean().item() * 2).bfloat16()
+        y3 = ops.conv1x1_astat(xd, wf, N, scale=sc.cuda(), shift=sh.cuda(), relu=True, residual=idn.cuda())
+        ref3 = F.relu(ref * sc + sh + idn.float())
+        assert (y3.float().cpu() - ref3).abs().max().item() <= 1.5e-2 * ref3.abs().max().item()
+        y3n = ops.conv1x1_astat(xd, wf, N, scale=sc.cuda(), shift=sh.cuda(), relu=False, residual=idn.cuda())
+        ref3n = ref * sc + sh + idn.float()
+        assert (y3n.float().cpu() - ref3n).abs().max().item() <= 1.5e-2 * ref3n.abs().max().item()
+        y0r = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16), 1, 1, 1, 0, scale=sc.cuda(), shift=sh.cuda(), relu=True, residual=idn.cuda())
+        assert (y3.float() - y0r.float()).abs().max().item() <= 2.0 ** -7 * ref3.abs().max().item()
+        with pytest.raises(Exception):
+            ops.conv1x1_astat(xd, wf, N, relu=False, residual=idn.cuda())          # the residual form needs scale / shift
 
 
 @pytest.mark.parametrize("eight", [False, True])
