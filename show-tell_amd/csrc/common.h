@@ -40,6 +40,35 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return *reinterpret_cast<const uint32_t*>(&b);
 }
 
+// Output stores of the streaming / convolution kernels (data the storing kernel never reads again).  ST_STORE_POLICY is a BUILD knob
+// (make CXXFLAGS+=-DST_STORE_POLICY=1): 0 = plain stores (lines stay dirty in the XCD's L2 and are written back at the end of the
+// kernel, which the next kernel on the stream waits for: tools/launch_probe.hip measured 1.1 - 2.6 us per launch for 13 - 51 MB
+// outputs), 1 = `sc1` write-through stores (the bytes leave L2 while the kernel is still computing), 2 = `nt`.  `base` must be
+// wave-uniform (it becomes a buffer resource in SGPRs), the byte offset is per lane and must stay below 2^31.
+#ifndef ST_STORE_POLICY
+#define ST_STORE_POLICY 0
+#endif
+__device__ __forceinline__ void st_out_store16(void* base, long off_bytes, const u32x4& v) {
+#if ST_STORE_POLICY == 1
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off_bytes, 0, 16);      // aux 16 = sc1
+#elif ST_STORE_POLICY == 2
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + off_bytes));
+#else
+  *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + off_bytes) = v;
+#endif
+}
+__device__ __forceinline__ void st_out_store8(void* base, long off_bytes, const u32x2& v) {
+#if ST_STORE_POLICY == 1
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off_bytes, 0, 16);
+#elif ST_STORE_POLICY == 2
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(reinterpret_cast<char*>(base) + off_bytes));
+#else
+  *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(base) + off_bytes) = v;
+#endif
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }

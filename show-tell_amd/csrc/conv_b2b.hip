@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C2 == 256 && N3 <= 64) ? 2 : 1
         for (int i = 0; i < NI; ++i) {
           const int m = g * SM + ir + IRS * i;
           const u32x4 v = *reinterpret_cast<const u32x4*>(xt + (ir + IRS * i) * XPIX + ic * 16);
-          if (m < a.M && k < a.spb) *reinterpret_cast<u32x4*>(a.xout + (size_t)m * C2 + ic * 8) = v;
+          if (m < a.M && k < a.spb) st_out_store16(a.xout, ((long)m * C2 + ic * 8) * 2, v);
         }
       }
       if constexpr (G2) {
@@ -279,9 +279,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C2 == 256 && N3 <= 64) ? 2 : 1
               for (int e = 0; e < 4; ++e) v[4 * j + e] = acc3[i][j][e];
 #pragma unroll
             for (int c = 0; c < NC3; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
-            bf16_t* dst = a.y + (size_t)m * N3 + cb3;
-            if constexpr (NTW3 == 1) *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            else *reinterpret_cast<u32x4*>(dst) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            const long dst = ((long)m * N3 + cb3) * 2;
+            if constexpr (NTW3 == 1) st_out_store8(a.y, dst, u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
+            else st_out_store16(a.y, dst, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
           }
         }
       }

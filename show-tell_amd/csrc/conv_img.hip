@@ -281,7 +281,7 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
   }
   int ho = r0, wo = r16 + wm * TMW * 16;
   while (wo >= Wp) { wo -= Wp; ++ho; }
-  bf16_t* yimg = a.y + (size_t)img * a.H * a.W * a.N + cb;
+  const long yimg = ((long)img * a.H * a.W * a.N + cb) * 2;           // byte offset into a.y (st_out_store16: uniform base + lane offset)
 #pragma unroll
   for (int i = 0; i < TMW; ++i) {
     const bool valid = wo < a.W && ho < r0 + rows;
@@ -301,14 +301,14 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
           for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
         }
       }
-      bf16_t* dst = yimg + (size_t)(ho * a.W + wo) * a.N;
+      const long dst = yimg + (long)(ho * a.W + wo) * a.N * 2;
       if constexpr (NTW == 1) {
-        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        st_out_store8(a.y, dst, u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
       } else {
 #pragma unroll
         for (int h = 0; h < NTW / 2; ++h)
-          *reinterpret_cast<u32x4*>(dst + 8 * h) = u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
-                                                         pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+          st_out_store16(a.y, dst + 16 * h, u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                                  pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])});
       }
     }
     wo += 16;
@@ -606,16 +606,15 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
             for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
           }
         }
-        const size_t off = (size_t)m * a.N + cb;
-        bf16_t* dst = a.y + off;
+        const long dst = ((long)m * a.N + cb) * 2;
         if (a.y) {                                     // y == NULL: statistics only (st_conv_b2b recomputes the output where it is consumed)
         if constexpr (NTW == 1) {
-          *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          st_out_store8(a.y, dst, u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
         } else {
 #pragma unroll
           for (int h = 0; h < NTW / 2; ++h)
-            *reinterpret_cast<u32x4*>(dst + 8 * h) = u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
-                                                           pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+            st_out_store16(a.y, dst + 16 * h, u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                                    pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])});
         }
         }
       }
@@ -790,11 +789,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
         }
       }
-      bf16_t* dst = a.y + (size_t)m * a.N + cb;
+      const long dst = ((long)m * a.N + cb) * 2;
 #pragma unroll
       for (int h = 0; h < NTW / 2; ++h)
-        *reinterpret_cast<u32x4*>(dst + 8 * h) = u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
-                                                       pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+        st_out_store16(a.y, dst + 16 * h, u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                                pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])});
     }
   }
   if (a.stats) {
@@ -984,8 +983,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
         }
       }
-      *reinterpret_cast<u32x4*>(a.y + (size_t)m * a.N + ch0 * CW + cb) =
-          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      st_out_store16(a.y, ((long)m * a.N + ch0 * CW + cb) * 2,
+                     u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
     }
   };
   auto stats_park = [&](int ch) {                                    // per-channel sums of chunk `ch` -> LDS (flushed once at the end)

@@ -184,7 +184,13 @@ __global__ __launch_bounds__(256) void bn_act_reg_kernel(st_bn_act_desc d) {
 #pragma unroll
       for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], 0.f);
     }
-    Vec<T>::store(y + i * N, v);
+    if constexpr (sizeof(T) == 2) {
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+      if (d.rows * C * 2 < (1L << 31)) st_out_store16(y, i * 16, o);
+      else *reinterpret_cast<u32x4*>(y + i * N) = o;
+    } else Vec<T>::store(y + i * N, v);
 #pragma unroll
     for (int k = 0; k < N; ++k) { v[k] = nv[k]; rv[k] = nrv[k]; }
   }
