@@ -175,6 +175,29 @@ typedef struct {
  * ntw = N / 64 -- what st_conv1x1_wreg_supported returns for these layers today; a caller that packs another ntw gets wrong channels. */
 int st_conv_b2b_supported(int C1, int C2, int N);
 int st_conv_b2b(const st_conv_b2b_desc* d, void* stream);
+/* conv3 of a 14 x 14 Bottleneck (C1 = 256 -> C2 = 1024), the block's end, and conv1 of the NEXT block (C2 -> N = 256) in one kernel
+ * (csrc/conv_c3c1.hip; torchvision Bottleneck.forward twice over, reference cnn.py:46):
+ *   x_out = relu(bn3(conv3(a2)) + identity),   y = conv1_next(x_out)
+ * conv3's output channels are conv1's K dimension: each finished 128-channel chunk of x is stored once AND is one K-slab of conv1
+ * (through LDS); x is never read back.  Replaces st_conv1x1_astat + st_bn_act + st_conv1x1_kstream.
+ *   train (bn3_stats given): a2 = relu(batchnorm(x2; bn2_*)) (bn2_stats NULL: x2 is already normalised); bn3 from the batch statistics of
+ *     conv3's output, which a STATISTICS-ONLY st_conv1x1_astat call (y == NULL) over the same x2 / w3_frag produces first; `stats` receives
+ *     [sum | sumsq] of y.  x_out and y are bit-identical to the three-kernel path.
+ *   eval (scale3 / shift3 / scale1 / shift1 given, no statistics): a2 = x2, x_out = relu(conv3 * scale3 + shift3 + identity),
+ *     y = conv1(x_out) * scale1 + shift1 (ReLU if relu1).
+ * x2: [rows][256], identity / x_out: [rows][1024], y: [rows][256], all bf16.  w3_frag: st_pack_conv_weight_frag(ntw = 2) (the layout
+ * st_conv1x1_astat uses), w1_frag: ntw = 4 (st_conv1x1_kstream's). */
+typedef struct {
+  const void* x2; const void* w3_frag; const void* identity; void* x_out; const void* w1_frag; void* y;
+  float* stats; int stats_replicas;
+  const float* bn2_stats; const float* bn2_gamma; const float* bn2_beta; int bn2_replicas;
+  const float* bn3_stats; const float* bn3_gamma; const float* bn3_beta; int bn3_replicas;
+  float count; float eps;
+  const float* scale3; const float* shift3; const float* scale1; const float* shift1; int relu1;
+  long rows; int C1, C2, N;
+} st_conv_c3c1_desc;
+int st_conv_c3c1_supported(int C1, int C2, int N);
+int st_conv_c3c1(const st_conv_c3c1_desc* d, void* stream);
 /* The activation-stationary sibling for (C, N) = (256, 1024) / (512, 2048) (conv3 of the layer3 / layer4 Bottlenecks): a
  * workgroup keeps its 112 x C rows in LDS (producer's BatchNorm + ReLU applied once per element) and walks all N output
  * channels barrier-free, the epilogue of one 128-channel chunk under the next chunk's MFMAs.  Same descriptor (weights packed with the

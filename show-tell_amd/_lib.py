@@ -56,6 +56,16 @@ class ConvB2bDesc(C.Structure):
                 ("count", c_f), ("eps", c_f), ("rows", c_l), ("C1", c_i), ("C2", c_i), ("N", c_i)]
 
 
+class ConvC3c1Desc(C.Structure):
+    _fields_ = [("x2", c_p), ("w3_frag", c_p), ("identity", c_p), ("x_out", c_p), ("w1_frag", c_p), ("y", c_p),
+                ("stats", c_p), ("stats_replicas", c_i),
+                ("bn2_stats", c_p), ("bn2_gamma", c_p), ("bn2_beta", c_p), ("bn2_replicas", c_i),
+                ("bn3_stats", c_p), ("bn3_gamma", c_p), ("bn3_beta", c_p), ("bn3_replicas", c_i),
+                ("count", c_f), ("eps", c_f),
+                ("scale3", c_p), ("shift3", c_p), ("scale1", c_p), ("shift1", c_p), ("relu1", c_i),
+                ("rows", c_l), ("C1", c_i), ("C2", c_i), ("N", c_i)]
+
+
 class BnActDesc(C.Structure):
     _fields_ = [("x", c_p), ("y", c_p), ("res", c_p), ("stats", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("res_stats", c_p), ("res_gamma", c_p),

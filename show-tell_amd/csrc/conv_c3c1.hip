@@ -1,0 +1,391 @@
+// conv3 of a layer3 Bottleneck, the block's end, and conv1 of the NEXT block in ONE kernel (gfx950 / MI355X, bf16):
+//
+//     raw3 = conv3( a2 )                     1x1, 256 -> 1024     a2 = relu(bn2(raw2)) (train: applied in the fill) | conv2's eval output
+//     x    = relu( bn3(raw3) + identity )     the block's output = the next identity                 -> written once (x_out)
+//     y    = conv1_next( x )                  1x1, 1024 -> 256     (+ batch statistics | folded bn1 + ReLU)  -> written once
+//
+// (torchvision Bottleneck.forward twice over, reference cnn.py:46.)  Why one kernel: at 14 x 14 the three launches it replaces --
+// st_conv1x1_astat (30 us), the block-end st_bn_act pass (28 us, pure HBM time: 154 MB) and st_conv1x1_kstream (22 us, bound by the
+// L2 -> CU path: it re-reads x) -- spend more time around their MFMAs than in them (profiles/r03a_layer_table_train.csv: 2.1 - 2.8 x
+// their floors).  The observation that makes the fusion cheap: conv3's OUTPUT channels are conv1's K dimension.  A workgroup that
+// owns 112 rows walks conv3's 1024 output channels in chunks of 128 (the activation-stationary walk of conv1x1_astat_kernel); each
+// finished chunk -- bn3, + identity, ReLU, rounded to bf16: 112 x 128 values of x -- is at once (a) stored to x_out and (b) written to
+// a two-slot LDS slab where it is one 128-deep K-slab of conv1: acc1[112 x 256] += x_chunk . W1[:, chunk].  x is never read back,
+// the 154-MB normalise pass rides under MFMAs, conv1's activations never cross the L2 -> CU path, and three launch boundaries
+// become one.
+//   Train mode needs bn3's batch statistics BEFORE the walk: they come from a statistics-only pass of conv3 (st_conv1x1_astat with
+// y == NULL over the same inputs; conv3 is computed twice, 13 GFLOP); the accumulators are rounded to bf16 before bn3 exactly as
+// the stored raw tensor was, so x_out and y are BIT-IDENTICAL to st_conv1x1_astat -> st_bn_act -> st_conv1x1_kstream (tests assert it).
+//   Eval mode (folded BatchNorms, no statistics): x = relu(raw3 * scale3 + shift3 + identity) as st_conv1x1_astat's residual
+// epilogue forms it, y = relu(conv1(x) * scale1 + shift1): a layer3 block is two launches (conv2, this).
+//
+// Structure (4 waves, one per SIMD, one workgroup per CU; 224 workgroups at B = 128):
+//   fill      112 x 256 rows of a2 -> LDS (padded rows), bn3 scale / shift of all 1024 channels -> LDS
+//   per chunk c (straight-line, fully unrolled; ONE barrier per chunk):
+//     A(c)    conv3: 8 K-steps x 14 MFMAs per wave (32 channels x 112 rows), filters through a 6-K-step register ring
+//     B(c-1)  conv1 partial over slab (c-1): 4 K-steps x 28 MFMAs per wave (64 channels x 112 rows), filters through a 4-K-step ring,
+//             with E(c) -- the epilogue of A(c): identity (requested a chunk ahead), bn3, ReLU, bf16, x_out store, slab write --
+//             spread two 16-row tiles per K-step under B's MFMAs
+//   end       acc1 -> statistics | scale / shift / ReLU -> y
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+struct C3Args {
+  const bf16_t* x2; const bf16_t* w3; const bf16_t* res; bf16_t* xout; const bf16_t* w1; bf16_t* y;
+  float* stats; int srep;                                            // train: statistics of y [srep][2 x 256]
+  const float* s2; const float* g2; const float* b2; int s2rep;      // train: bn2 of x2 (NULL: x2 is already normalised)
+  const float* s3; const float* g3; const float* b3; int s3rep;      // train: bn3 from batch statistics
+  const float* sc3; const float* sh3;                                // eval: folded bn3
+  const float* sc1; const float* sh1; int relu1;                     // eval: folded bn1 of the next block (+ ReLU) on y
+  float count, eps;
+  int M;
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_rot_(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum_(float v) {
+  v += dpp_rot_<0x128>(v); v += dpp_rot_<0x124>(v); v += dpp_rot_<0x122>(v); v += dpp_rot_<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void bn_relu_chunk_(u32x4& v, const float* sc, const float* sh) {   // conv_img.hip's bn_relu_chunk: same arithmetic
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float lo = fmaxf(__uint_as_float(v[d] << 16) * sc[2 * d] + sh[2 * d], 0.f);
+    const float hi = fmaxf(__uint_as_float(v[d] & 0xffff0000u) * sc[2 * d + 1] + sh[2 * d + 1], 0.f);
+    v[d] = pack_bf16x2(lo, hi);
+  }
+}
+
+// Every global access of the kernel goes through a buffer resource (uniform base in SGPRs + ONE 32-bit lane offset + a compile-time
+// constant): with plain 64-bit pointers the fully unrolled walk kept ~20 row / fragment pointers alive (40 VGPRs, spilled) and spent
+// two VALU instructions of address arithmetic per load beside the MFMAs.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t rs, int voff, int coff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, coff, 0);
+}
+__device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t rs, int voff, int coff, const u32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, coff, ST_STORE_POLICY == 1 ? 16 : 0);
+}
+
+constexpr int K3 = 256, N3 = 1024, N1 = 256;                         // conv3: K3 -> N3, conv1: N3 -> N1
+constexpr int TM = 7, BM = 16 * TM;                                  // 112 rows per workgroup
+constexpr int PIX3 = 2 * K3 + 32;                                    // padded LDS row of the conv3 input (bytes)
+constexpr int CW = 128, PIXS = 2 * CW + 32;                          // chunk width (conv3 output channels = conv1 K-slab), padded slab row
+constexpr int NCHUNK = N3 / CW;                                      // 8
+constexpr int KS3 = K3 / 32, KSB = CW / 32, KS1 = N3 / 32;           // K-steps: conv3 per chunk (8), conv1 per slab (4), conv1 in all (32)
+constexpr int NTW3 = 2, NTW1 = 4;                                    // 16-channel tiles per wave: conv3 (32 of a chunk's 128), conv1 (64 of 256)
+constexpr int WR3 = 6, WR1 = 4;                                      // filter rings (K-steps in flight)
+constexpr int A2_BYTES = BM * PIX3, SLAB_BYTES = BM * PIXS;
+constexpr int C3_LDS = A2_BYTES + 2 * SLAB_BYTES + 2 * N3 * 4 + 2 * K3 * 4;
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_c3c1_kernel(C3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* slab = smem + A2_BYTES;
+  float* coef3 = reinterpret_cast<float*>(smem + A2_BYTES + 2 * SLAB_BYTES);     // [scale(N3) | shift(N3)]
+  float* coef2 = coef3 + 2 * N3;                                                // [scale(K3) | shift(K3)] (train)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bm;
+  {   // workgroups that share an XCD (equal blockIdx % 8) take neighbouring row blocks
+    const int nblk = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    bm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs_w3 = rsrc_of(a.w3), rs_w1 = rsrc_of(a.w1), rs_res = rsrc_of(a.res), rs_x = rsrc_of(a.xout), rs_y = rsrc_of(a.y);
+  // conv3 K-step g of the walk (chunk g / KS3, K-step g % KS3): this wave's tiles (chunk * 4 + wid) * NTW3 + j   (conv1x1_astat_kernel's layout);
+  // fragment (T, ks) sits at ((T * KS + ks) * 64 + lane) * 16 bytes
+  const int voff3 = (wid * NTW3 * KS3 * 64 + lane) * 16, voff1 = (wid * NTW1 * KS1 * 64 + lane) * 16;
+  auto wfrag3 = [&](int g, int j) { return bload16(rs_w3, voff3, ((((g / KS3) * 4) * NTW3 + j) * KS3 + g % KS3) * 1024); };
+  // conv1 K-step h (0 .. KS1): this wave's tiles wid * NTW1 + j                                                    (conv1x1_kstream_kernel's layout)
+  auto wfrag1 = [&](int h, int j) { return bload16(rs_w1, voff1, (j * KS1 + h) * 1024); };
+
+  u32x4 wq3[WR3][NTW3], wq1[WR1][NTW1];
+#pragma unroll
+  for (int g = 0; g < WR3; ++g)
+#pragma unroll
+    for (int j = 0; j < NTW3; ++j) wq3[g][j] = wfrag3(g, j);
+
+  // the identity pieces of a chunk, in accumulator layout (8 consecutive channels of row i * 16 + r16), requested one chunk ahead;
+  // rows past M re-read row M - 1 (never stored): every load of the kernel is unconditional
+  constexpr int NC3 = 4 * NTW3;                                       // 8
+  int rowoff[TM]; bool mok[TM];                                       // byte offset of (row, this lane's first channel of a chunk) in identity / x_out
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = bm * BM + i * 16 + r16;
+    mok[i] = m < a.M;
+    rowoff[i] = ((mok[i] ? m : a.M - 1) * N3 + wid * 32 + NC3 * q4) * 2;
+  }
+  u32x4 rres[TM];
+  auto res_request = [&](int ch, int i) { rres[i] = bload16(rs_res, rowoff[i], ch * CW * 2); };
+
+  // ---- fill: 112 x 256 rows of the conv3 input, every load in flight before the first LDS write ------------------------------------
+  {
+    constexpr int CH8 = K3 / 8, RPP = 256 / CH8, NL = BM / RPP;      // 32 chunks per row, 8 rows per pass, 14 loads per thread
+    const int cch = tid % CH8, lrow = tid / CH8;
+    u32x4 v[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int m = bm * BM + lrow + i * RPP;
+      m = m < a.M ? m : a.M - 1;
+      v[i] = *reinterpret_cast<const u32x4*>(a.x2 + (size_t)m * K3 + cch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) res_request(0, i);
+#pragma unroll
+    for (int h = 0; h < WR1; ++h)
+#pragma unroll
+      for (int j = 0; j < NTW1; ++j) wq1[h][j] = wfrag1(h, j);
+    if constexpr (TRAIN) {
+      const float inv = 1.0f / a.count;
+      for (int c = tid; c < N3; c += 256) {
+        float sm = 0.f, sq = 0.f;
+        for (int r = 0; r < a.s3rep; ++r) { sm += a.s3[(size_t)r * 2 * N3 + c]; sq += a.s3[(size_t)r * 2 * N3 + N3 + c]; }
+        bn_scale_shift(sm, sq, inv, a.g3[c], a.b3[c], a.eps, coef3[c], coef3[N3 + c]);
+      }
+      if (a.s2) {
+        for (int c = tid; c < K3; c += 256) {
+          float sm = 0.f, sq = 0.f;
+          for (int r = 0; r < a.s2rep; ++r) { sm += a.s2[(size_t)r * 2 * K3 + c]; sq += a.s2[(size_t)r * 2 * K3 + K3 + c]; }
+          bn_scale_shift(sm, sq, inv, a.g2[c], a.b2[c], a.eps, coef2[c], coef2[K3 + c]);
+        }
+        __syncthreads();
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = coef2[cch * 8 + e]; sh[e] = coef2[K3 + cch * 8 + e]; }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) bn_relu_chunk_(v[i], sc, sh);
+      }
+    } else {
+      for (int c = tid; c < N3; c += 256) { coef3[c] = a.sc3[c]; coef3[N3 + c] = a.sh3[c]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<u32x4*>(smem + (lrow + i * RPP) * PIX3 + cch * 16) = v[i];
+  }
+  __syncthreads();
+
+  // ---- the walk -----------------------------------------------------------------------------------------------------------------
+  const char* abase3 = smem + r16 * PIX3 + q4 * 16;
+  const char* abases = slab + r16 * PIXS + q4 * 16;
+  auto read_a3 = [&](u32x4 (&f)[TM], int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f[i] = *reinterpret_cast<const u32x4*>(abase3 + i * 16 * PIX3 + ks * 64);
+  };
+  auto read_a1 = [&](u32x4 (&f)[TM], int buf, int kk) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f[i] = *reinterpret_cast<const u32x4*>(abases + buf * SLAB_BYTES + i * 16 * PIXS + kk * 64);
+  };
+  f32x4 acc3[TM][NTW3], acc1[TM][NTW1];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW1; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sc[NC3], sh[NC3];                                             // bn3 scale / shift of this lane's 8 channels of the chunk in E
+  auto coef_load = [&](int ch) {
+    const float* cs = coef3 + ch * CW + wid * 32 + NC3 * q4;
+#pragma unroll
+    for (int e = 0; e < NC3; e += 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(cs + e), h4 = *reinterpret_cast<const f32x4*>(cs + N3 + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { sc[e + q] = s4[q]; sh[e + q] = h4[q]; }
+    }
+  };
+  // E: tile i of chunk ch -> x (bn3 + identity + ReLU, bf16) -> x_out and the slab; then this tile's identity register requests chunk ch + 1
+  auto tile_e = [&](int ch, int i) {
+    float v[NC3];
+#pragma unroll
+    for (int j = 0; j < NTW3; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * j + e] = acc3[i][j][e];
+    if constexpr (TRAIN) {   // the raw tensor the separate path stores is bf16: round here too (bit-identical x)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t p = pack_bf16x2(v[2 * d], v[2 * d + 1]);
+        v[2 * d] = __uint_as_float(p << 16); v[2 * d + 1] = __uint_as_float(p & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      v[2 * d] = fmaxf(__builtin_fmaf(v[2 * d], sc[2 * d], sh[2 * d]) + __uint_as_float(rres[i][d] << 16), 0.f);
+      v[2 * d + 1] = fmaxf(__builtin_fmaf(v[2 * d + 1], sc[2 * d + 1], sh[2 * d + 1]) + __uint_as_float(rres[i][d] & 0xffff0000u), 0.f);
+    }
+    const u32x4 o = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(slab + (ch & 1) * SLAB_BYTES + (i * 16 + r16) * PIXS + (wid * 32 + NC3 * q4) * 2) = o;
+    if (mok[i]) bstore16(rs_x, rowoff[i], ch * CW * 2, o);
+    if (ch + 1 < NCHUNK) res_request(ch + 1, i);
+  };
+
+  // operand double buffer: K-step parity picks the buffer; every iteration runs an even number of K-steps (8 | 8 + 4 | 4), so the
+  // parity of a step is the parity of its index inside its phase
+  u32x4 fa0[TM], fa1[TM];
+  read_a3(fa0, 0);
+#pragma clang loop unroll(full)
+  for (int c = 0; c <= NCHUNK; ++c) {
+    if (c < NCHUNK) {
+      // ---- A(c): conv3 chunk c ------------------------------------------------------------------------------------------------
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW3; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma clang loop unroll(full)
+      for (int ks = 0; ks < KS3; ++ks) {
+        const int g = c * KS3 + ks;
+        u32x4 (&fa)[TM] = (ks & 1) ? fa1 : fa0;
+        u32x4 (&fn)[TM] = (ks & 1) ? fa0 : fa1;
+        if (ks + 1 < KS3) read_a3(fn, ks + 1);
+        else if (c >= 1) read_a1(fn, (c - 1) & 1, 0);               // B(c-1) comes next: its slab was completed at the last barrier
+        else read_a3(fn, 0);                                         // c == 0: A(1) comes next (after E(0) and the barrier; the rows are static)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW3; ++j) acc3[i][j] = mfma_bf16(wq3[g % WR3][j], fa[i], acc3[i][j]);
+        if (g + WR3 < NCHUNK * KS3) {
+#pragma unroll
+          for (int j = 0; j < NTW3; ++j) wq3[g % WR3][j] = wfrag3(g + WR3, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (c == 0) {                                                     // no conv1 work yet: E(0) stands alone, once per workgroup
+      coef_load(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) tile_e(0, i);
+    } else {
+      // ---- B(c-1): conv1 partial over slab (c-1) & 1, with E(c) spread under its MFMAs ------------------------------------------
+      if (c < NCHUNK) coef_load(c);
+#pragma clang loop unroll(full)
+      for (int kk = 0; kk < KSB; ++kk) {
+        const int h = (c - 1) * KSB + kk;
+        u32x4 (&fa)[TM] = (kk & 1) ? fa1 : fa0;
+        u32x4 (&fn)[TM] = (kk & 1) ? fa0 : fa1;
+        if (kk + 1 < KSB) read_a1(fn, (c - 1) & 1, kk + 1);
+        else if (c + 1 < NCHUNK) read_a3(fn, 0);                     // A(c+1) comes next (static rows: safe across the barrier)
+        // (c + 1 == NCHUNK: B(NCHUNK-1) comes next and its slab is only complete at the barrier: read after it)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW1; ++j) acc1[i][j] = mfma_bf16(wq1[h % WR1][j], fa[i], acc1[i][j]);
+        if (h + WR1 < KS1) {
+#pragma unroll
+          for (int j = 0; j < NTW1; ++j) wq1[h % WR1][j] = wfrag1(h + WR1, j);
+        }
+        if (c < NCHUNK) {
+          tile_e(c, 2 * kk);
+          if (2 * kk + 1 < TM) tile_e(c, 2 * kk + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (c < NCHUNK) {
+      __syncthreads();                                                // slab c & 1 is complete; everybody has left slab (c-1) & 1
+      if (c + 1 == NCHUNK) read_a1(fa0, c & 1, 0);                   // B(NCHUNK-1) starts right behind this barrier
+    }
+  }
+
+  // ---- conv1 epilogue: accumulators -> (statistics | scale / shift / ReLU) -> bf16 -> two 16-byte stores per row ----------------------
+  constexpr int NC1 = 4 * NTW1;                                       // 16 consecutive channels per lane
+  const int cb1 = wid * NTW1 * 16 + NC1 * q4;
+  float es[NC1], ess[NC1], scv[NC1], shv[NC1];
+#pragma unroll
+  for (int c = 0; c < NC1; ++c) { es[c] = 0.f; ess[c] = 0.f; scv[c] = 1.f; shv[c] = 0.f; }
+  if constexpr (!TRAIN) {
+#pragma unroll
+    for (int c = 0; c < NC1; ++c) { scv[c] = a.sc1[cb1 + c]; shv[c] = a.sh1[cb1 + c]; }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (mok[i]) {
+      float v[NC1];
+#pragma unroll
+      for (int j = 0; j < NTW1; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * j + e] = acc1[i][j][e];
+      if constexpr (TRAIN) {
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) v[c] = v[c] * scv[c] + shv[c];
+        if (a.relu1) {
+#pragma unroll
+          for (int c = 0; c < NC1; ++c) v[c] = fmaxf(v[c], 0.f);
+        }
+      }
+      const int dst = ((bm * BM + i * 16 + r16) * N1 + cb1) * 2;
+#pragma unroll
+      for (int h = 0; h < NTW1 / 2; ++h)
+        bstore16(rs_y, dst, 16 * h, u32x4{pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                          pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])});
+    }
+  }
+  if (TRAIN && a.stats) {
+    float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * N1 : 0);
+#pragma unroll
+    for (int c = 0; c < NC1; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
+    float* sred = reinterpret_cast<float*>(smem);                     // [2][N1]; the conv3 rows are dead
+    __syncthreads();
+    if (r16 == 0) {
+#pragma unroll
+      for (int c = 0; c < NC1; ++c) { sred[cb1 + c] = es[c]; sred[N1 + cb1 + c] = ess[c]; }
+    }
+    __syncthreads();
+    for (int tt = tid; tt < 2 * N1; tt += 256) atomicAdd(sdst + tt, sred[tt]);
+  }
+}
+
+template <bool TRAIN>
+int launch_c3c1(C3Args& a, hipStream_t st, double flops) {
+  static_assert(C3_LDS <= 160 * 1024, "LDS");
+  static int attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c3c1_kernel<TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[dev] = 1;
+  }
+  StProfScope prof(22, flops, st);
+  hipLaunchKernelGGL((conv_c3c1_kernel<TRAIN>), dim3((a.M + BM - 1) / BM), dim3(256), C3_LDS, st, a);
+  prof.end(st);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int st_conv_c3c1_supported(int C1, int C2, int N) { return (C1 == K3 && C2 == N3 && N == N1) ? 1 : 0; }
+
+extern "C" int st_conv_c3c1(const st_conv_c3c1_desc* d, void* stream) {
+  ST_CHECK(d && d->x2 && d->w3_frag && d->identity && d->x_out && d->w1_frag && d->y, "st_conv_c3c1: null pointer");
+  ST_CHECK(st_conv_c3c1_supported(d->C1, d->C2, d->N), "st_conv_c3c1: unsupported geometry %d -> %d -> %d", d->C1, d->C2, d->N);
+  ST_CHECK(d->rows > 0 && d->rows * (long)N3 * 2 < (1L << 31), "st_conv_c3c1: bad row count %ld", d->rows);
+  ST_CHECK(d->x_out != d->identity && d->x_out != d->x2 && d->y != d->x2, "st_conv_c3c1: outputs must not alias inputs");
+  const bool train = d->bn3_stats != nullptr;
+  if (train) {
+    ST_CHECK(d->bn3_gamma && d->bn3_beta && d->count > 0.f && !d->scale3 && !d->scale1, "st_conv_c3c1: train mode takes bn3 statistics + gamma / beta (and no folded coefficients)");
+    ST_CHECK(!d->bn2_stats || (d->bn2_gamma && d->bn2_beta), "st_conv_c3c1: bn2_stats comes with bn2_gamma, bn2_beta");
+  } else {
+    ST_CHECK(d->scale3 && d->shift3 && d->scale1 && d->shift1 && !d->bn2_stats && !d->stats, "st_conv_c3c1: eval mode takes folded scale / shift for bn3 and the next bn1, no statistics");
+  }
+  auto rep = [](int r) { return r > 1 ? r : 1; };
+  ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->bn2_replicas >= 0 && d->bn2_replicas <= 1024 && d->bn3_replicas >= 0 && d->bn3_replicas <= 1024, "st_conv_c3c1: bad replicas");
+  C3Args a{};
+  a.x2 = reinterpret_cast<const bf16_t*>(d->x2); a.w3 = reinterpret_cast<const bf16_t*>(d->w3_frag); a.res = reinterpret_cast<const bf16_t*>(d->identity);
+  a.xout = reinterpret_cast<bf16_t*>(d->x_out); a.w1 = reinterpret_cast<const bf16_t*>(d->w1_frag); a.y = reinterpret_cast<bf16_t*>(d->y);
+  a.stats = d->stats; a.srep = d->stats_replicas;
+  a.s2 = d->bn2_stats; a.g2 = d->bn2_gamma; a.b2 = d->bn2_beta; a.s2rep = rep(d->bn2_replicas);
+  a.s3 = d->bn3_stats; a.g3 = d->bn3_gamma; a.b3 = d->bn3_beta; a.s3rep = rep(d->bn3_replicas);
+  a.sc3 = d->scale3; a.sh3 = d->shift3; a.sc1 = d->scale1; a.sh1 = d->shift1; a.relu1 = d->relu1;
+  a.count = d->count; a.eps = d->eps; a.M = (int)d->rows;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const double flops = 2.0 * (double)d->rows * ((double)K3 * N3 + (double)N3 * N1);
+  return train ? launch_c3c1<true>(a, st, flops) : launch_c3c1<false>(a, st, flops);
+}

@@ -983,8 +983,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
         }
       }
-      st_out_store16(a.y, ((long)m * a.N + ch0 * CW + cb) * 2,
-                     u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+      if (a.y)   // y == NULL: statistics only (st_conv_c3c1 recomputes the output where it is consumed)
+        st_out_store16(a.y, ((long)m * a.N + ch0 * CW + cb) * 2,
+                       u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
     }
   };
   auto stats_park = [&](int ch) {                                    // per-channel sums of chunk `ch` -> LDS (flushed once at the end)
@@ -1491,7 +1492,7 @@ extern "C" int st_conv1x1_astat_supported(int K, int N) {
 }
 
 extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
-  ST_CHECK(d && d->x && d->w_frag && d->y, "st_conv1x1_astat: null pointer");
+  ST_CHECK(d && d->x && d->w_frag && (d->y || (d->stats && !d->scale)), "st_conv1x1_astat: null pointer (y may be NULL only when statistics are asked for)");
   ST_CHECK(st_conv1x1_astat_supported(d->C, d->N), "st_conv1x1_astat: unsupported geometry C=%d N=%d", d->C, d->N);
   const bool strided = d->stride > 1;
   ST_CHECK(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->stride >= 1, "st_conv1x1_astat: bad geometry");

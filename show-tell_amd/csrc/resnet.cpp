@@ -367,7 +367,29 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
       }
-      if (fz && fz->b2b) {
+      if (fz && fz->b2b && r->convs[fz->ci].cout == 1024) {
+        // 14 x 14 blocks: conv3 of the previous block (statistics-only pass already run in train mode), its block end and this conv1 in
+        // ONE kernel (conv_c3c1.hip) -- conv3's output chunks are this conv1's K-slabs
+        const ConvL& pc = r->convs[fz->ci];
+        const ConvL& c2 = r->convs[fz->c2ci];
+        st_conv_c3c1_desc k;
+        memset(&k, 0, sizeof(k));
+        k.x2 = fz->raw2; k.w3_frag = reinterpret_cast<const char*>(weights) + pc.woff_frag * es; k.identity = fz->res; k.x_out = fz->xout;
+        k.w1_frag = g.w_frag; k.y = y;
+        if (train) {
+          k.stats = g.stats; k.stats_replicas = g.stats_replicas;
+          k.bn2_stats = stats + tab.soff[fz->c2ci]; k.bn2_gamma = bn_gamma + c2.bnoff; k.bn2_beta = bn_beta + c2.bnoff; k.bn2_replicas = tab.rep[fz->c2ci];
+          k.bn3_stats = stats + tab.soff[fz->ci]; k.bn3_gamma = bn_gamma + pc.bnoff; k.bn3_beta = bn_beta + pc.bnoff; k.bn3_replicas = tab.rep[fz->ci];
+          k.count = tab.count[fz->ci]; k.eps = eps;
+        } else {
+          k.scale3 = fscale + pc.bnoff; k.shift3 = fshift + pc.bnoff; k.scale1 = d.scale; k.shift1 = d.shift; k.relu1 = d.relu;
+        }
+        k.rows = (long)B * hin * win; k.C1 = pc.cin; k.C2 = pc.cout; k.N = c.cout;
+        if (st_conv_c3c1(&k, stream)) return 1;
+        log_launch("conv_c3c1", "conv3 + block end (bn3 + identity + relu) + next conv1", pc.cin, c.cout, 1, 1, hin, win,
+                   2.0 * k.rows * ((double)pc.cin * pc.cout + (double)c.cin * c.cout),
+                   ((double)k.rows * (pc.cin + 2.0 * pc.cout + c.cout) + (double)pc.cin * pc.cout + (double)c.cin * c.cout) * es);
+      } else if (fz && fz->b2b) {
         const ConvL& pc = r->convs[fz->ci];
         const ConvL& c2 = r->convs[fz->c2ci];
         st_conv_b2b_desc k;
@@ -568,7 +590,19 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         res = wide[dsb];
       }
       bool defer = false, b2b = false;
-      if (train && use_img && kfuse_env && bi + 1 < r->blocks.size()) {
+      // 14 x 14 blocks (256 -> 1024 -> next conv1 1024 -> 256), train AND eval: conv3 + block end + next conv1 as one kernel
+      // (st_conv_c3c1).  Train: conv3 runs here as a statistics-only pass (y == NULL); an identity that still needs its own BatchNorm
+      // (the block after a downsample conv) keeps the separate path.  Eval: conv3 is not launched at all.
+      static const bool c3c1_env = [] { const char* e = getenv("ST_C3C1"); return !e || atoi(e) != 0; }();
+      bool c3c1 = false;
+      if (use_img && c3c1_env && bi + 1 < r->blocks.size()) {
+        const BlockL& nb = r->blocks[bi + 1];
+        const ConvL& n1 = r->convs[nb.c1];
+        c3c1 = n1.k == 1 && n1.stride == 1 && c3.k == 1 && c3.stride == 1 && c3.cout == n1.cin && st_conv_c3c1_supported(c3.cin, c3.cout, n1.cout) &&
+               c3.ntw == 2 && use_astat(c3) && n1.ntw == 4 && (!train || b.ds < 0) && (long)B * h2 * w2 * c3.cout * 2 < (1L << 31);
+      }
+      if (c3c1) { defer = true; b2b = true; }
+      else if (train && use_img && kfuse_env && bi + 1 < r->blocks.size()) {
         const BlockL& nb = r->blocks[bi + 1];
         const ConvL& n1 = r->convs[nb.c1];
         defer = n1.k == 1 && n1.stride == 1 && n1.cin == 256 && n1.ntw > 0 && !use_astat(n1) && c3.cout == n1.cin &&
@@ -585,7 +619,8 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       // B = 128) is neither written nor read
       const bool lite = !defer && train && use_img && b2b_env && fuse2 && c3.k == 1 && c3.stride == 1 && c3.ntw == 2 && !use_astat(c3) &&
                         c3.ntw == st_conv1x1_wreg_supported(c3.cin, c3.cout) && st_conv_b2b_supported(c3.cin, c3.cout, 0);
-      if (conv(b.c3, narrow[1], h2, w2, (b2b || lite) ? nullptr : wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
+      if (c3c1 && !train) { h3 = h2; w3 = w2; }                  // eval: conv3 is computed where it is consumed (the next block's conv1 launch)
+      else if (conv(b.c3, narrow[1], h2, w2, (b2b || lite) ? nullptr : wide[oth], res, 1, &h3, &w3, fuse2 ? b.c2 : -1)) return 1;
       if (defer) pend = Pending{true, b.c3, res, b.ds, oth, b.ds >= 0 ? dsb : cur, b2b, narrow[1], b.c2};
       else if (lite) {
         const ConvL& c2l = r->convs[b.c2];

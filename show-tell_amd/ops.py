@@ -334,17 +334,47 @@ def conv_b2b(raw2, w3_frag, identity, w1_frag, N, bn2, bn3, count, id_bn=None, e
     return x_out, out
 
 
+def conv_c3c1(x2, w3_frag, identity, w1_frag, bn2=None, bn3=None, count=None, eps=1e-5, stats=None, stats_replicas=0,
+              scale3=None, shift3=None, scale1=None, shift1=None, relu1=True, x_out=None, out=None):
+    """st_conv_c3c1: x = relu(bn3(conv3(a2)) + identity) (-> x_out), y = conv1_next(x) for the 14 x 14 Bottlenecks (256 -> 1024 -> 256).
+    train: bn3 = dict(stats, gamma, beta[, replicas]) (+ bn2 for a raw x2), count; eval: scale3 / shift3 / scale1 / shift1.  Returns (x_out, y)."""
+    from ._lib import ConvC3c1Desc
+    _dev(x2, w3_frag, identity, w1_frag, stats, x_out, out, scale3, shift3, scale1, shift1)
+    rows = x2.numel() // x2.shape[-1]
+    if x_out is None:
+        x_out = torch.empty_like(identity)
+    if out is None:
+        out = torch.empty(*x2.shape[:-1], 256, device=x2.device, dtype=torch.bfloat16)
+    d = ConvC3c1Desc()
+    d.x2, d.w3_frag, d.identity, d.x_out, d.w1_frag, d.y = x2.data_ptr(), w3_frag.data_ptr(), identity.data_ptr(), x_out.data_ptr(), w1_frag.data_ptr(), out.data_ptr()
+    d.stats, d.stats_replicas = (stats.data_ptr() if stats is not None else None), int(stats_replicas)
+    for nm, bn in (("bn2", bn2), ("bn3", bn3)):
+        if bn is not None:
+            _dev(bn["stats"], bn["gamma"], bn["beta"])
+            setattr(d, nm + "_stats", bn["stats"].data_ptr()); setattr(d, nm + "_gamma", bn["gamma"].data_ptr()); setattr(d, nm + "_beta", bn["beta"].data_ptr())
+            setattr(d, nm + "_replicas", int(bn.get("replicas", 0)))
+    d.count, d.eps = float(count or 0.0), float(eps)
+    for nm, t in (("scale3", scale3), ("shift3", shift3), ("scale1", scale1), ("shift1", shift1)):
+        if t is not None:
+            setattr(d, nm, t.data_ptr())
+    d.relu1 = int(relu1)
+    d.rows, d.C1, d.C2, d.N = rows, x2.shape[-1], identity.shape[-1], 256
+    check(lib().st_conv_c3c1(C.byref(d), _stream()), "st_conv_c3c1")
+    return x_out, out
+
+
 def conv1x1_astat_supported(Cin, N):
     return int(lib().st_conv1x1_astat_supported(Cin, N))
 
 
-def conv1x1_astat(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, in_bn=None, out=None, residual=None):
+def conv1x1_astat(x, w_frag, N, stride=1, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, in_bn=None, out=None, residual=None,
+                  stats_only=False):
     """Activation-stationary 1x1 conv (st_conv1x1_astat): stride 1 with (C, N) in {(256, 1024), (512, 2048)}, stride 2 with (256, 512) /
     (512, 1024); w_frag = pack_conv_weight_frag(w, conv1x1_astat_supported(C, N))."""
     _dev(x, w_frag, stats, scale, shift, out, residual)
     B, H, W, Cc = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    if out is None:
+    if out is None and not stats_only:                  # stats_only: y == NULL, only the [sum | sumsq] statistics are produced
         out = torch.empty(B, Ho, Wo, N, device=x.device, dtype=torch.bfloat16)
     d = Conv1x1WregDesc(_p(x), _p(w_frag), _p(out), _p(residual), _p(stats), int(stats_replicas), _p(scale), _p(shift), int(relu),
                         None, None, None, 0.0, 0.0, 0, B, H, W, Cc, N, int(stride))

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from showtell_amd import ops
 from showtell_amd._lib import lib
-variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5]
+variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 6]
 B, h, dt, NL, dev = 128, 14, torch.bfloat16, 22, "cuda"
 x0 = torch.relu(torch.randn(B, h, h, 1024, device=dev)).to(dt)
 W1 = [(torch.randn(256, 1024, device=dev) / 32).to(dt) for _ in range(NL)]
@@ -38,6 +38,24 @@ s3rs = [torch.zeros(4, 2048, device=dev) for _ in range(2)]
 
 def fwd(variant):
     x = x0
+    if variant == 6:
+        # conv1 (first block only) -> per block: conv2 image-resident, conv3 statistics-only pass, then conv3 + block end + the NEXT block's
+        # conv1 in one kernel (st_conv_c3c1); the last block ends with the separate pass
+        ops.conv1x1_kstream(x, W1k[0], 256, stats=s1r, stats_replicas=16, out=y1)
+        ident = x
+        for l in range(NL):
+            ops.conv3x3_img(y1, W2i[l], 256, stats=s2r, stats_replicas=16, out=y2, in_bn=dict(stats=s1r, gamma=g256, beta=b256, count=n, replicas=16))
+            bn2 = dict(stats=s2r, gamma=g256, beta=b256, count=n, replicas=16)
+            if l + 1 < NL:
+                ops.conv1x1_astat(y2, W3a[l], 1024, stats=s3rs[l & 1], stats_replicas=4, in_bn=bn2, stats_only=True)
+                xn = xbuf[l & 1]
+                ops.conv_c3c1(y2, W3a[l], ident, W1k[l + 1], bn2=bn2, bn3=dict(stats=s3rs[l & 1], gamma=g1k, beta=b1k, replicas=4), count=n,
+                              stats=s1r, stats_replicas=16, x_out=xn, out=y1)
+                ident = xn
+            else:
+                ops.conv1x1_astat(y2, W3a[l], 1024, stats=s3r, stats_replicas=4, out=y3, in_bn=bn2)
+                ops.bn_act(y3, g1k, b1k, stats=s3r, stats_replicas=4, count=n, relu=True, res=ident, out=y3)
+        return
     for l in range(NL):
         if variant >= 4:
             # x holds the previous block's output only for l == 0; afterwards (raw3, ident) of the previous block are pending
