@@ -89,6 +89,44 @@ __device__ __forceinline__ void bn_scale_shift(float sum, float sumsq, float inv
   sh = __builtin_fmaf(-mean, s, beta);
 }
 
+// [sum, sumsq] of channel c over `rep` replicas of a [rep][2C] statistics block, added in replica order (the order every consumer
+// uses: the scale / shift of a layer must come out bit-identical in all of them).  Four replicas per round trip: the eight loads of a
+// batch are unconditional (replica index clamped, the surplus masked to zero), so a thread pays ONE memory latency per four replicas --
+// the rolled `for (r < rep) { sm += ..; sq += ..; }` it replaces paid one per replica (1 - 2 us of every kernel prologue at rep = 4).
+__device__ __forceinline__ void stat_sum(const float* stats, int rep, int C, int c, float& sm, float& sq) {
+  sm = 0.f; sq = 0.f;
+  for (int r0 = 0; r0 < rep; r0 += 4) {
+    float a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + q < rep ? r0 + q : rep - 1;
+      a[q] = stats[(size_t)r * 2 * C + c]; b[q] = stats[(size_t)r * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sm += r0 + q < rep ? a[q] : 0.f; sq += r0 + q < rep ? b[q] : 0.f; }
+  }
+}
+// the same for NCH channels c0, c0 + cs, .. of one thread at once (all 8 NCH loads of a batch in flight together)
+template <int NCH>
+__device__ __forceinline__ void stat_sums(const float* stats, int rep, int C, int c0, int cs, float (&sm)[NCH], float (&sq)[NCH]) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) { sm[k] = 0.f; sq[k] = 0.f; }
+  for (int r0 = 0; r0 < rep; r0 += 4) {
+    float a[NCH][4], b[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + q < rep ? r0 + q : rep - 1;
+        a[k][q] = stats[(size_t)r * 2 * C + c0 + k * cs]; b[k][q] = stats[(size_t)r * 2 * C + C + c0 + k * cs];
+      }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { sm[k] += r0 + q < rep ? a[k][q] : 0.f; sq[k] += r0 + q < rep ? b[k][q] : 0.f; }
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -149,17 +149,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && C2 == 256 && N3 <= 64) ? 2 : 1
     const float inv = 1.0f / a.count;
     for (int c = tid; c < C1; c += NT) {
       float sm = 0.f, sq = 0.f;
-      for (int r = 0; r < a.s2rep; ++r) { sm += a.s2[(size_t)r * 2 * C1 + c]; sq += a.s2[(size_t)r * 2 * C1 + C1 + c]; }
+      stat_sum(a.s2, a.s2rep, C1, c, sm, sq);
       bn_scale_shift(sm, sq, inv, a.g2[c], a.b2[c], a.eps, coef[c], coef[C1 + c]);
     }
     for (int c = tid; c < C2; c += NT) {
       float sm = 0.f, sq = 0.f;
-      for (int r = 0; r < a.s3rep; ++r) { sm += a.s3[(size_t)r * 2 * C2 + c]; sq += a.s3[(size_t)r * 2 * C2 + C2 + c]; }
+      stat_sum(a.s3, a.s3rep, C2, c, sm, sq);
       bn_scale_shift(sm, sq, inv, a.g3[c], a.b3[c], a.eps, coef[2 * C1 + c], coef[2 * C1 + C2 + c]);
       float s2_ = 1.f, h2_ = 0.f;
       if (rbn) {
         float rm = 0.f, rq = 0.f;
-        for (int r = 0; r < a.srrep; ++r) { rm += a.sr[(size_t)r * 2 * C2 + c]; rq += a.sr[(size_t)r * 2 * C2 + C2 + c]; }
+        stat_sum(a.sr, a.srrep, C2, c, rm, rq);
         bn_scale_shift(rm, rq, inv, a.gr[c], a.br[c], a.eps, s2_, h2_);
       }
       coef[2 * C1 + 2 * C2 + c] = s2_; coef[2 * C1 + 3 * C2 + c] = h2_;

@@ -41,6 +41,7 @@ struct C3Args {
   const float* sc1; const float* sh1; int relu1;                     // eval: folded bn1 of the next block (+ ReLU) on y
   float count, eps;
   int M;
+  unsigned long long* stamps;   // debug (tools/c3_stamps.py): per-wave s_memtime at the phase boundaries, normally NULL
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_rot_(float v) {
@@ -101,6 +102,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
   const int r16 = lane & 15, q4 = lane >> 4;
+#define C3_STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  C3_STAMP(0);
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
   const __amdgpu_buffer_rsrc_t rs_w3 = rsrc_of(a.w3), rs_w1 = rsrc_of(a.w1), rs_res = rsrc_of(a.res), rs_x = rsrc_of(a.xout), rs_y = rsrc_of(a.y);
   // conv3 K-step g of the walk (chunk g / KS3, K-step g % KS3): this wave's tiles (chunk * 4 + wid) * NTW3 + j   (conv1x1_astat_kernel's layout);
   // fragment (T, ks) sits at ((T * KS + ks) * 64 + lane) * 16 bytes
@@ -108,6 +112,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto wfrag3 = [&](int g, int j) { return bload16(rs_w3, voff3, ((((g / KS3) * 4) * NTW3 + j) * KS3 + g % KS3) * 1024); };
   // conv1 K-step h (0 .. KS1): this wave's tiles wid * NTW1 + j                                                    (conv1x1_kstream_kernel's layout)
   auto wfrag1 = [&](int h, int j) { return bload16(rs_w1, voff1, (j * KS1 + h) * 1024); };
+
+  // ---- coefficient inputs FIRST: they head the in-order load queue, so consuming them (below, after every tile / filter load has been
+  // issued) waits for them alone.  Train: the first four replicas of bn3's statistics for this thread's four channels and of bn2's for
+  // its one channel (K3 == blockDim), gamma / beta; all unconditional (a NULL bn2 reads bn3's arrays and is ignored).
+  float sa[4][4], sb[4][4], gg[4], bb[4], s2a[4], s2b[4], g2v = 1.f, b2v = 0.f;
+  if constexpr (TRAIN) {
+    const float* s2p = a.s2 ? a.s2 : a.s3;
+    const float* g2p = a.s2 ? a.g2 : a.g3;
+    const float* b2p = a.s2 ? a.b2 : a.b3;
+    const int rep2 = a.s2 ? a.s2rep : 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r3 = q < a.s3rep ? q : a.s3rep - 1, r2 = q < rep2 ? q : rep2 - 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { sa[k][q] = a.s3[(size_t)r3 * 2 * N3 + tid + 256 * k]; sb[k][q] = a.s3[(size_t)r3 * 2 * N3 + N3 + tid + 256 * k]; }
+      s2a[q] = s2p[(size_t)r2 * 2 * K3 + tid]; s2b[q] = s2p[(size_t)r2 * 2 * K3 + K3 + tid];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { gg[k] = a.g3[tid + 256 * k]; bb[k] = a.b3[tid + 256 * k]; }
+    g2v = g2p[tid]; b2v = b2p[tid];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { gg[k] = a.sc3[tid + 256 * k]; bb[k] = a.sh3[tid + 256 * k]; }
+  }
 
   u32x4 wq3[WR3][NTW3], wq1[WR1][NTW1];
 #pragma unroll
@@ -147,16 +175,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < NTW1; ++j) wq1[h][j] = wfrag1(h, j);
     if constexpr (TRAIN) {
       const float inv = 1.0f / a.count;
-      for (int c = tid; c < N3; c += 256) {
-        float sm = 0.f, sq = 0.f;
-        for (int r = 0; r < a.s3rep; ++r) { sm += a.s3[(size_t)r * 2 * N3 + c]; sq += a.s3[(size_t)r * 2 * N3 + N3 + c]; }
-        bn_scale_shift(sm, sq, inv, a.g3[c], a.b3[c], a.eps, coef3[c], coef3[N3 + c]);
+      {   // bn3 scale / shift of all 1024 channels (four per thread), replicas added in replica order (as every other consumer does)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float sm = 0.f, sq = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { sm += q < a.s3rep ? sa[k][q] : 0.f; sq += q < a.s3rep ? sb[k][q] : 0.f; }
+          for (int r = 4; r < a.s3rep; ++r) { sm += a.s3[(size_t)r * 2 * N3 + tid + 256 * k]; sq += a.s3[(size_t)r * 2 * N3 + N3 + tid + 256 * k]; }   // (the engine uses <= 4)
+          bn_scale_shift(sm, sq, inv, gg[k], bb[k], a.eps, coef3[tid + 256 * k], coef3[N3 + tid + 256 * k]);
+        }
       }
       if (a.s2) {
-        for (int c = tid; c < K3; c += 256) {
+        {
           float sm = 0.f, sq = 0.f;
-          for (int r = 0; r < a.s2rep; ++r) { sm += a.s2[(size_t)r * 2 * K3 + c]; sq += a.s2[(size_t)r * 2 * K3 + K3 + c]; }
-          bn_scale_shift(sm, sq, inv, a.g2[c], a.b2[c], a.eps, coef2[c], coef2[K3 + c]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { sm += q < a.s2rep ? s2a[q] : 0.f; sq += q < a.s2rep ? s2b[q] : 0.f; }
+          for (int r = 4; r < a.s2rep; ++r) { sm += a.s2[(size_t)r * 2 * K3 + tid]; sq += a.s2[(size_t)r * 2 * K3 + K3 + tid]; }
+          bn_scale_shift(sm, sq, inv, g2v, b2v, a.eps, coef2[tid], coef2[K3 + tid]);
         }
         __syncthreads();
         float sc[8], sh[8];
@@ -166,12 +201,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < NL; ++i) bn_relu_chunk_(v[i], sc, sh);
       }
     } else {
-      for (int c = tid; c < N3; c += 256) { coef3[c] = a.sc3[c]; coef3[N3 + c] = a.sh3[c]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { coef3[tid + 256 * k] = gg[k]; coef3[N3 + tid + 256 * k] = bb[k]; }
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i) *reinterpret_cast<u32x4*>(smem + (lrow + i * RPP) * PIX3 + cch * 16) = v[i];
   }
+  C3_STAMP(1);
   __syncthreads();
+  C3_STAMP(2);
 
   // ---- the walk -----------------------------------------------------------------------------------------------------------------
   const char* abase3 = smem + r16 * PIX3 + q4 * 16;
@@ -281,16 +319,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (c < NCHUNK) {
           tile_e(c, 2 * kk);
           if (2 * kk + 1 < TM) tile_e(c, 2 * kk + 1);
+          // E's VALU stream (accumulator reads, bn3, ReLU, packing: ~45 instructions per tile) does not depend on B's MFMAs: ask the
+          // scheduler to issue it BETWEEN them (an MFMA holds the issue port for 8 of its 16 cycles: ~2 other instructions fit per MFMA
+          // for free).  Left to itself the backend kept source order -- 28 MFMAs, then E -- and the two phases simply added up
+          // (stamps: B alone 0.98 us, E alone 1.0 us, B + E 2.2 us per chunk).
+#pragma unroll
+          for (int q = 0; q < TM * NTW1; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);        // up to four VALU
+            if (q < TM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the next K-step's operand reads, one per group
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (c < NCHUNK) {
+      C3_STAMP(3 + c);                                                // (before the barrier: own work of the iteration)
       __syncthreads();                                                // slab c & 1 is complete; everybody has left slab (c-1) & 1
       if (c + 1 == NCHUNK) read_a1(fa0, c & 1, 0);                   // B(NCHUNK-1) starts right behind this barrier
     }
   }
 
+  C3_STAMP(11);
   // ---- conv1 epilogue: accumulators -> (statistics | scale / shift / ReLU) -> bf16 -> two 16-byte stores per row ----------------------
   constexpr int NC1 = 4 * NTW1;                                       // 16 consecutive channels per lane
   const int cb1 = wid * NTW1 * 16 + NC1 * q4;
@@ -340,6 +390,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     for (int tt = tid; tt < 2 * N1; tt += 256) atomicAdd(sdst + tt, sred[tt]);
   }
+  C3_STAMP(12);
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#undef C3_STAMP
 }
 
 template <bool TRAIN>
@@ -384,7 +437,7 @@ extern "C" int st_conv_c3c1(const st_conv_c3c1_desc* d, void* stream) {
   a.s2 = d->bn2_stats; a.g2 = d->bn2_gamma; a.b2 = d->bn2_beta; a.s2rep = rep(d->bn2_replicas);
   a.s3 = d->bn3_stats; a.g3 = d->bn3_gamma; a.b3 = d->bn3_beta; a.s3rep = rep(d->bn3_replicas);
   a.sc3 = d->scale3; a.sh3 = d->shift3; a.sc1 = d->scale1; a.sh1 = d->shift1; a.relu1 = d->relu1;
-  a.count = d->count; a.eps = d->eps; a.M = (int)d->rows;
+  a.count = d->count; a.eps = d->eps; a.M = (int)d->rows; a.stamps = st_debug_stamps_ptr();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)d->rows * ((double)K3 * N3 + (double)N3 * N1);
   return train ? launch_c3c1<true>(a, st, flops) : launch_c3c1<false>(a, st, flops);

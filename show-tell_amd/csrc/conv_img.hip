@@ -145,8 +145,8 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
     if (xf_) {
       const float inv = 1.0f / a.in_count;
       for (int c = tid; c < C; c += 256) {
-        float sm = 0.f, sq = 0.f;
-        for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * C + c]; sq += a.in_stats[(size_t)r * 2 * C + C + c]; }
+        float sm, sq;
+        stat_sum(a.in_stats, a.in_srep, C, c, sm, sq);
         bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[C + c]);
       }
       __syncthreads();
@@ -189,8 +189,8 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
       if (xf && first) {
         const float inv = 1.0f / a.in_count;
         for (int c = tid; c < C; c += 256) {
-          float sm = 0.f, sq = 0.f;
-          for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * C + c]; sq += a.in_stats[(size_t)r * 2 * C + C + c]; }
+          float sm, sq;
+          stat_sum(a.in_stats, a.in_srep, C, c, sm, sq);
           bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[C + c]);
         }
         __syncthreads();
@@ -510,14 +510,14 @@ __global__ __launch_bounds__(256) void conv1x1_wreg_kernel(PwArgs a) {
     float* coef = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
     const float inv = 1.0f / a.in_count;
     for (int c = tid; c < K; c += 256) {
-      float sm = 0.f, sq = 0.f;
-      for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * K + c]; sq += a.in_stats[(size_t)r * 2 * K + K + c]; }
+      float sm, sq;
+      stat_sum(a.in_stats, a.in_srep, K, c, sm, sq);
       bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[K + c]);
       if constexpr (FUSE) {
         float s2 = 1.f, h2 = 0.f;
         if (rbn) {
-          float rm = 0.f, rq = 0.f;
-          for (int r = 0; r < a.res_srep; ++r) { rm += a.res_stats[(size_t)r * 2 * K + c]; rq += a.res_stats[(size_t)r * 2 * K + K + c]; }
+          float rm, rq;
+          stat_sum(a.res_stats, a.res_srep, K, c, rm, rq);
           bn_scale_shift(rm, rq, inv, a.res_gamma[c], a.res_beta[c], a.in_eps, s2, h2);
         }
         coef[2 * K + c] = s2; coef[3 * K + c] = h2;
@@ -908,8 +908,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (a.in_stats) {
       const float inv = 1.0f / a.in_count;
       for (int c = tid; c < K; c += 256) {
-        float sm = 0.f, sq = 0.f;
-        for (int r = 0; r < a.in_srep; ++r) { sm += a.in_stats[(size_t)r * 2 * K + c]; sq += a.in_stats[(size_t)r * 2 * K + K + c]; }
+        float sm, sq;
+        stat_sum(a.in_stats, a.in_srep, K, c, sm, sq);
         bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[K + c]);
       }
       __syncthreads();
@@ -1137,8 +1137,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {
     const float inv = 1.0f / a.f_count;
     for (int c = tid; c < K; c += 256) {
-      float sm = 0.f, sq = 0.f;
-      for (int r = 0; r < a.f_srep; ++r) { sm += a.f_stats[(size_t)r * 2 * K + c]; sq += a.f_stats[(size_t)r * 2 * K + K + c]; }
+      float sm, sq;
+      stat_sum(a.f_stats, a.f_srep, K, c, sm, sq);
       bn_scale_shift(sm, sq, inv, a.f_gamma[c], a.f_beta[c], a.f_eps, coef[c], coef[K + c]);
     }
   }
