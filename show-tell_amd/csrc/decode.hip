@@ -440,6 +440,7 @@ int gemm_nt(const void* a, int lda, const void* w, int ldw, void* y, int ldy, in
 // Greedy decoding keeps one arg-max key row per step (no re-arming between steps) for up to kFusedSteps steps, so that
 // layer 0 of step t+1 can gather its embedding rows from step t's keys itself (one launch less per step).
 constexpr int kFusedSteps = 64;
+constexpr int kPipeSteps = 32;     // the pipelined decoder's workspace is sized for up to this many steps (rnn.py:39: 25)
 
 extern "C" size_t st_rnn_greedy_workspace_bytes(const st_rnn_params* p, int B) {
   if (!p || B <= 0) return 0;
@@ -447,7 +448,8 @@ extern "C" size_t st_rnn_greedy_workspace_bytes(const st_rnn_params* p, int B) {
   const size_t hb = al((size_t)p->L * B * p->H * es);
   const int ng = p->cell == ST_CELL_GRU ? 3 : 4;
   return 4 * hb + al((size_t)B * p->E * es) + al((size_t)B * up8(p->V) * sizeof(float)) + al((size_t)B * kFusedSteps * sizeof(unsigned long long)) +
-         al((size_t)p->L * B * ng * p->H * sizeof(float));       // recurrent halves of the split step (gh)
+         al((size_t)p->L * B * ng * p->H * sizeof(float)) +      // recurrent halves of the split step (gh)
+         rnn_greedy_pipe_bytes(p, B, kPipeSteps);                // the pipelined decoder's buffers (0 when the configuration is not eligible)
 }
 
 extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, int steps, void* workspace, size_t workspace_bytes,
@@ -467,6 +469,17 @@ extern "C" int st_rnn_greedy(const st_rnn_params* p, const void* feat, int B, in
   char* xbuf = ws + 4 * hb;
   float* logits = reinterpret_cast<float*>(xbuf + al((size_t)B * E * es));
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(logits) + al((size_t)B * Vp * sizeof(float)));
+  // bf16 GRU at the BASELINE decoder shape: the whole loop as ONE persistent kernel, a layer per XCD (csrc/decode_pipe.hip); it gives
+  // up (rc 2) when the configuration is not eligible or the grid could not be made co-resident -- then the launch chain below runs
+  if (!logits_out && steps <= kPipeSteps) {
+    const size_t pipe_bytes = rnn_greedy_pipe_bytes(p, B, kPipeSteps);
+    if (pipe_bytes) {
+      const size_t base = st_rnn_greedy_workspace_bytes(p, B) - pipe_bytes;
+      const int rc = rnn_greedy_pipe(p, feat, B, steps, ws + base, pipe_bytes, ids_out, st);
+      if (rc == 0) return 0;
+      if (rc == 1) return 1;
+    }
+  }
   const bool fused = !logits_out && steps <= kFusedSteps;   // keys[t][B]; otherwise one row, re-armed by keys_to_ids_embed_kernel
   if (!logits_out && hipMemsetAsync(keys, 0, (size_t)B * (fused ? steps : 1) * sizeof(unsigned long long), st) != hipSuccess) { st_set_error("memset failed"); return 1; }
   const void* x = feat;

@@ -40,6 +40,25 @@ struct RnnBwdCell {                    // BPTT gate gradients of one (layer, tim
 };
 struct RnnBwdBatch { RnnBwdCell c[kRnnBatch]; };
 
+// One GRU unit (torch.nn.GRU, gate order r, z, n; reference rnn.py:32 / rnn.py:49):  x* = W_i* x + b_i*, h* = W_h* h + b_h*,
+//   r = s(xr + hr), z = s(xz + hz), n = tanh(xn + r hn), h' = (1 - z) n + z h.
+// ONE definition with explicit fused multiply-adds for every kernel that evaluates a cell (rnn_gemm_kernel, decode_pipe_kernel): the
+// launch-chain decoder and the pipelined decoder must produce the same bits (-ffp-contract=fast would otherwise fuse per call site).
+#ifdef __HIPCC__
+__device__ __forceinline__ float st_sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float st_gru_unit(float xr, float xz, float xn, float hr, float hz, float hn, float hprev, float& r, float& z, float& n) {
+  r = st_sigm(xr + hr);
+  z = st_sigm(xz + hz);
+  n = tanhf(__builtin_fmaf(r, hn, xn));
+  return __builtin_fmaf(z, hprev, (1.f - z) * n);
+}
+#endif
+
+// the pipelined (layer-per-XCD) greedy decoder, csrc/decode_pipe.hip: bytes it needs behind the launch chain's workspace (0: the
+// configuration stays on the launch chain) and the run itself (0: done, 1: error, 2: not run / gave up -- use the launch chain)
+size_t rnn_greedy_pipe_bytes(const st_rnn_params* p, int B, int steps);
+int rnn_greedy_pipe(const st_rnn_params* p, const void* feat, int B, int steps, void* ws, size_t ws_bytes, long* ids_out, hipStream_t st);
+
 int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st);
 int rnn_gemm_launch_batch(const RnnGemmArgs* cells, int ncells, int dtype, int epi, int has_x, hipStream_t st);
 int rnn_bwd_gates_launch_batch(const RnnBwdCell* cells, int ncells, int H, int cell_kind, int dtype, hipStream_t st);

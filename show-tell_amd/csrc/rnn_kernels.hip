@@ -270,10 +270,7 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
     for (int e = 0; e < 4; ++e) {
       const float hr = split ? ex[0][e] : sumH[0][e] + eb[0][e], hz = split ? ex[1][e] : sumH[1][e] + eb[1][e];
       hn[e] = split ? ex[2][e] : sumH[2][e] + eb[2][e];
-      r[e] = sigm(xg[0][e] + hr);
-      z[e] = sigm(xg[1][e] + hz);
-      nn[e] = tanhf(xg[2][e] + r[e] * hn[e]);
-      hnew[e] = (1.f - z[e]) * nn[e] + z[e] * hp[e];
+      hnew[e] = st_gru_unit(xg[0][e], xg[1][e], xg[2][e], hr, hz, hn[e], hp[e], r[e], z[e], nn[e]);
     }
     store4<T>(reinterpret_cast<T*>(a.hout) + (long)m * a.ldho + n, hnew);
     if (a.hout2) store4<T>(reinterpret_cast<T*>(a.hout2) + (long)m * a.ldho2 + n, hnew);

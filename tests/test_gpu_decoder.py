@@ -242,3 +242,28 @@ def test_optimizers_match_torch(kind):
     # the bf16 shadow follows the parameters
     for q in dev:
         assert torch.equal(q._st_shadow.float().cpu(), q.detach().bfloat16().float().cpu())
+
+
+@pytest.mark.parametrize("B,L,V", [(128, 5, 10000), (8, 5, 10000), (33, 5, 10000), (256, 5, 10000), (64, 3, 9000), (40, 1, 12000), (16, 5, 777)])
+def test_pipelined_greedy_decoder_equals_launch_chain(B, L, V, monkeypatch):
+    """rnn.py:37-58 at the BASELINE decoder shape (E = H = 512, bf16): the persistent layer-per-XCD decoder (csrc/decode_pipe.hip)
+    must return the launch chain's token ids bit for bit -- same MFMA order, same gate function, same arg-max keys -- for full and
+    ragged chains (B not a multiple of 32), fewer layers (more vocabulary XCDs) and other vocabulary sizes; and the fp32 / oracle
+    agreement the launch chain is tested for carries over."""
+    from showtell_amd.rnn import RNN
+    E = H = 512
+    sd = R.init_decoder_params(E, H, V, L, "gru", seed=11 + B)
+    sd["linear.weight"] *= 6.0
+    m = RNN(E, H, V, L, dtype=torch.bfloat16); m.load_state_dict(sd); m = m.cuda().eval()
+    feat = torch.randn(B, E, generator=torch.Generator().manual_seed(B)).cuda()
+    monkeypatch.setenv("ST_DECODE_PIPE", "0")
+    ids_chain = m.sentence_index(feat)
+    monkeypatch.setenv("ST_DECODE_PIPE", "1")
+    ids_pipe = m.sentence_index(feat)
+    ids_pipe2 = m.sentence_index(feat)                     # a second run on a reused workspace (stale buffers must not matter)
+    torch.cuda.synchronize()
+    assert ids_pipe.shape == ids_chain.shape == (B, 25)
+    assert torch.equal(ids_pipe, ids_chain)
+    assert torch.equal(ids_pipe2, ids_chain)
+    assert ids_chain.min().item() >= 0 and ids_chain.max().item() < V
+    assert len(torch.unique(ids_chain)) > 5                # not a degenerate decode
