@@ -106,6 +106,27 @@ __device__ __forceinline__ void stat_sum(const float* stats, int rep, int C, int
     for (int q = 0; q < 4; ++q) { sm += r0 + q < rep ? a[q] : 0.f; sq += r0 + q < rep ? b[q] : 0.f; }
   }
 }
+// Split form for kernel prologues: `stat_head_issue` REQUESTS the first four replicas of one channel (plus gamma / beta) -- call it before
+// the kernel's tile / filter loads so that these few dwords head the in-order load queue; `stat_head_finish` adds them up in replica
+// order (replicas beyond four are fetched there: the engine uses <= 4) and returns the BatchNorm scale / shift.  Consuming them waits for
+// them alone, not for the tile loads issued in between, and the coefficient arithmetic overlaps the tiles' flight.
+struct StatHead { float a[4], b[4], g, be; };
+__device__ __forceinline__ void stat_head_issue(StatHead& h, const float* stats, int rep, int C, int c, const float* gamma, const float* beta) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = q < rep ? q : rep - 1;
+    h.a[q] = stats[(size_t)r * 2 * C + c]; h.b[q] = stats[(size_t)r * 2 * C + C + c];
+  }
+  h.g = gamma[c]; h.be = beta[c];
+}
+__device__ __forceinline__ void stat_head_finish(const StatHead& h, const float* stats, int rep, int C, int c, float inv_count, float eps, float& sc, float& sh) {
+  float sm = 0.f, sq = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { sm += q < rep ? h.a[q] : 0.f; sq += q < rep ? h.b[q] : 0.f; }
+  for (int r = 4; r < rep; ++r) { sm += stats[(size_t)r * 2 * C + c]; sq += stats[(size_t)r * 2 * C + C + c]; }
+  bn_scale_shift(sm, sq, inv_count, h.g, h.be, eps, sc, sh);
+}
+
 // the same for NCH channels c0, c0 + cs, .. of one thread at once (all 8 NCH loads of a batch in flight together)
 template <int NCH>
 __device__ __forceinline__ void stat_sums(const float* stats, int rep, int C, int c0, int cs, float (&sm)[NCH], float (&sq)[NCH]) {

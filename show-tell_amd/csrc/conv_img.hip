@@ -102,6 +102,13 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
 
 #define IMG_STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   IMG_STAMP(0);
+  // the producer's BatchNorm statistics of this thread's channel(s) head the load queue (stat_head_issue, common.h): C / 256 channels per thread
+  constexpr int NSH = C > 256 ? C / 256 : 1;
+  StatHead shd[NSH];
+  if (a.in_stats) {
+#pragma unroll
+    for (int k = 0; k < NSH; ++k) { const int c = (tid + 256 * k) % C; stat_head_issue(shd[k], a.in_stats, a.in_srep, C, c, a.in_gamma, a.in_beta); }
+  }
   // the first filter fragments are requested before the fill: they land while the band is staged
   const int r16 = lane & 15, q4 = lane >> 4;
   const int wn = MS == 1 ? wid : (wid & 1), wm = MS == 1 ? 0 : (wid >> 1);
@@ -144,10 +151,10 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
     float sc0[8], sh0[8];
     if (xf_) {
       const float inv = 1.0f / a.in_count;
-      for (int c = tid; c < C; c += 256) {
-        float sm, sq;
-        stat_sum(a.in_stats, a.in_srep, C, c, sm, sq);
-        bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[C + c]);
+#pragma unroll
+      for (int k = 0; k < NSH; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C) stat_head_finish(shd[k], a.in_stats, a.in_srep, C, c, inv, a.in_eps, coef[c], coef[C + c]);
       }
       __syncthreads();
 #pragma unroll
@@ -188,10 +195,10 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
       }
       if (xf && first) {
         const float inv = 1.0f / a.in_count;
-        for (int c = tid; c < C; c += 256) {
-          float sm, sq;
-          stat_sum(a.in_stats, a.in_srep, C, c, sm, sq);
-          bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[C + c]);
+#pragma unroll
+        for (int k = 0; k < NSH; ++k) {
+          const int c = tid + 256 * k;
+          if (c < C) stat_head_finish(shd[k], a.in_stats, a.in_srep, C, c, inv, a.in_eps, coef[c], coef[C + c]);
         }
         __syncthreads();
 #pragma unroll
@@ -868,6 +875,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define AS_STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   AS_STAMP(0);
   if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  constexpr int NSH = K > 256 ? K / 256 : 1;                          // producer's statistics first (stat_head_issue, common.h)
+  StatHead shd[NSH];
+  if (a.in_stats) {
+#pragma unroll
+    for (int k = 0; k < NSH; ++k) { const int c = (tid + 256 * k) % K; stat_head_issue(shd[k], a.in_stats, a.in_srep, K, c, a.in_gamma, a.in_beta); }
+  }
   u32x4 wq[WR][NTW];
 #pragma unroll
   for (int g = 0; g < WR; ++g)
@@ -907,10 +920,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (a.in_stats) {
       const float inv = 1.0f / a.in_count;
-      for (int c = tid; c < K; c += 256) {
-        float sm, sq;
-        stat_sum(a.in_stats, a.in_srep, K, c, sm, sq);
-        bn_scale_shift(sm, sq, inv, a.in_gamma[c], a.in_beta[c], a.in_eps, coef[c], coef[K + c]);
+#pragma unroll
+      for (int k = 0; k < NSH; ++k) {
+        const int c = tid + 256 * k;
+        if (c < K) stat_head_finish(shd[k], a.in_stats, a.in_srep, K, c, inv, a.in_eps, coef[c], coef[K + c]);
       }
       __syncthreads();
       float sc[8], sh[8];
