@@ -275,6 +275,8 @@ def main():
         prefixes[20] = ("stem_pool_kernel<",)
         names[21] = "conv_b2b_kernel (conv3 recomputed + bn3 + identity + ReLU (+ next conv1) in one pass, csrc/conv_b2b.hip)"
         prefixes[21] = ("conv_b2b_kernel<",)
+        names[22] = "conv_c3c1_kernel (14x14 Bottlenecks: conv3 256->1024 + block end + next conv1 1024->256 in one kernel, csrc/conv_c3c1.hip)"
+        prefixes[22] = ("conv_c3c1_kernel<",)
         v = max(range(32), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12 if ms[v] > 0 else 0.0
         tot_ms, tot_fl = sum(ms), sum(fl)
@@ -422,10 +424,14 @@ def main():
                 import csv, glob
                 f_ = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_decode_hbm_traffic.csv")))[-1]
                 rows_ = [r_ for r_ in csv.reader(open(f_)) if r_]
+                pipe_ = [float(r_[4]) for r_ in rows_ if r_[0].startswith("decode_pipe_kernel")]
                 cell_ = [float(r_[4]) for r_ in rows_ if r_[0].startswith("rnn_gemm_kernel<bool") and ", true, 1>" in r_[0]]
                 voc_ = [float(r_[4]) for r_ in rows_ if r_[0] == "vocab_argmax_lds_kernel"]
-                if cell_ and voc_:
+                if pipe_:                                             # one launch = the whole 25-step decode
+                    dec_traffic = round(pipe_[0] * 1e6 / 25)
+                elif cell_ and voc_:
                     dec_traffic = round((L * cell_[0] + voc_[0]) * 1e6)
+                if dec_traffic is not None:
                     dec_traffic_src = "profiles/" + os.path.basename(f_) + " (committed PMC passes of an earlier run, NOT this run)"
             except Exception:
                 dec_traffic = None
