@@ -275,6 +275,8 @@ def main():
         prefixes[20] = ("stem_pool_kernel<",)
         names[21] = "conv_b2b_kernel (conv3 recomputed + bn3 + identity + ReLU (+ next conv1) in one pass, csrc/conv_b2b.hip)"
         prefixes[21] = ("conv_b2b_kernel<",)
+        names[23] = "conv3x3s2_kstream_kernel (the three stride-2 3x3 convs, K-streaming implicit GEMM, csrc/conv_s2.hip)"
+        prefixes[23] = ("conv3x3s2_kstream_kernel<",)
         names[22] = "conv_c3c1_kernel (14x14 Bottlenecks: conv3 256->1024 + block end + next conv1 1024->256 in one kernel, csrc/conv_c3c1.hip)"
         prefixes[22] = ("conv_c3c1_kernel<",)
         v = max(range(32), key=lambda i: ms[i])

@@ -106,6 +106,11 @@ typedef struct {
  * low byte = 16-channel tiles per wave, bits 8.. = channel halves of the K order); 0: use st_conv */
 int st_conv3x3_img_supported(int H, int W, int C, int N);
 int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream);
+/* The stride-2 siblings (3x3, pad 1, stride 2: conv2 of the first block of layer2 / layer3 / layer4; csrc/conv_s2.hip): a K-streaming implicit
+ * GEMM with gathered rows, (C, N) in {(128, 128), (256, 256), (512, 512)}.  Same descriptor (H, W = input size, y: [B][(H-1)/2+1][(W-1)/2+1][N]);
+ * w_frag: st_pack_conv_weight_frag(.., KH = KW = 3, ntw = st_conv3x3_s2_supported(C, N)). */
+int st_conv3x3_s2_supported(int C, int N);
+int st_conv3x3_s2(const st_conv3x3_img_desc* d, void* stream);
 /* ------------------------------------------------------------------------------------
  * Pointwise (1x1, stride 1 or 2) convolution with the filter slice held in registers, bf16, C <= 512 input channels
  * (conv3 / downsample of torchvision's Bottleneck and the narrow conv1s, reference cnn.py:46; csrc/conv_img.hip).

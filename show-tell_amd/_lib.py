@@ -117,6 +117,8 @@ _SIGS = {
     "st_conv_batch": ([C.POINTER(ConvDesc), c_i, c_p], c_i),
     "st_conv3x3_img_supported": ([c_i, c_i, c_i, c_i], c_i),
     "st_conv3x3_img": ([C.POINTER(Conv3x3ImgDesc), c_p], c_i),
+    "st_conv3x3_s2_supported": ([c_i, c_i], c_i),
+    "st_conv3x3_s2": ([C.POINTER(Conv3x3ImgDesc), c_p], c_i),
     "st_conv1x1_wreg_supported": ([c_i, c_i], c_i),
     "st_conv1x1_wreg": ([C.POINTER(Conv1x1WregDesc), c_p], c_i),
     "st_conv1x1_kfuse": ([C.POINTER(Conv1x1KfuseDesc), c_p], c_i),

@@ -141,6 +141,11 @@ extern "C" int st_resnet_create(int version, int dtype, st_resnet** out) {
       c.ntw = st_conv3x3_img_supported(8, 8, cin, cout);
       if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * 9 * cin; }
     }
+    // the stride-2 3x3 convs of the bottleneck nets (conv2 of the first block of layer2 / 3 / 4): K-streaming kernel, fragment-major copy
+    if (dtype == ST_BF16 && k == 3 && s == 2 && p == 1) {
+      c.ntw = st_conv3x3_s2_supported(cin, cout);
+      if (c.ntw > 0) { c.woff_frag = r->wtotal; r->wtotal += (size_t)cout * 9 * cin; }
+    }
     // pointwise layers with <= 512 input channels: fragment-major copy for the register-resident-filter kernel (st_conv1x1_wreg);
     // a stride-2 512-channel layer the activation-stationary kernel does not take stays with st_conv (measured slower on wreg)
     if (dtype == ST_BF16 && k == 1 && p == 0 && (use_astat(c) || !(s == 2 && cin == 512))) {
@@ -304,6 +309,8 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   int stats_used = 0;   // floats handed out so far
   static const bool img_env = [] { const char* e = getenv("ST_CONV_IMG"); return !e || atoi(e) != 0; }();
   const bool use_img = img_env && dt == ST_BF16;   // ST_CONV_IMG=0: every 3x3 through st_conv (A/B switch)
+  static const bool s2_env = [] { const char* e = getenv("ST_CONV_S2"); return !e || atoi(e) != 0; }();
+  const bool use_s2 = use_img && s2_env;            // ST_CONV_S2=0: the stride-2 3x3 convs stay on st_conv
 
   // conv: train -> raw output + statistics; eval -> folded BN (+residual)(+ReLU) in the epilogue
   // in_ci >= 0 (train): x is the RAW output of conv in_ci; this conv reads relu(bn_{in_ci}(x)) in its loader
@@ -439,7 +446,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
           log_launch("conv1x1_wreg", y ? "1x1" : "1x1 statistics only", c.cin, c.cout, 1, c.stride, hin, win, fl, by);
         }
       }
-    } else if (c.ntw > 0 && c.k == 3 && use_img && !d.residual && st_conv3x3_img_supported(hin, win, c.cin, c.cout) == c.ntw) {
+    } else if (c.ntw > 0 && c.k == 3 && c.stride == 1 && use_img && !d.residual && st_conv3x3_img_supported(hin, win, c.cin, c.cout) == c.ntw) {
       // image-resident 3x3 (conv_img.hip): the producer's BatchNorm + ReLU ride in its fill, replicated statistics in and out
       st_conv3x3_img_desc g;
       memset(&g, 0, sizeof(g));
@@ -459,6 +466,26 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       if (st_conv3x3_img(&g, stream)) return 1;
       log_launch("conv3x3_img", "3x3", c.cin, c.cout, 3, 1, hin, win, 2.0 * B * hin * win * 9.0 * c.cin * c.cout,
                  ((double)B * hin * win * (c.cin + c.cout) + 9.0 * c.cin * c.cout) * es);
+    } else if (c.ntw > 0 && c.k == 3 && c.stride == 2 && use_s2 && !d.residual && st_conv3x3_s2_supported(c.cin, c.cout) == c.ntw &&
+               (long)B * hin * win * c.cin * 2 < (1L << 31)) {
+      // stride-2 3x3 (conv_s2.hip): K-streaming implicit GEMM with gathered rows; bn1 + ReLU of the producer in its loader
+      st_conv3x3_img_desc g;
+      memset(&g, 0, sizeof(g));
+      g.x = x; g.w_frag = reinterpret_cast<const char*>(weights) + c.woff_frag * es; g.y = y;
+      g.B = B; g.H = hin; g.W = win; g.C = c.cin; g.N = c.cout;
+      g.in_stats = d.in_stats; g.in_gamma = d.in_gamma; g.in_beta = d.in_beta; g.in_count = d.in_count; g.in_eps = d.in_eps;
+      g.in_stats_replicas = in_ci >= 0 ? tab.rep[in_ci] : 0;
+      g.scale = d.scale; g.shift = d.shift; g.relu = d.relu;
+      if (train) {
+        int rep = 1;
+        while (rep < 4 && (rep * 2) * 2 * c.cout <= kStatsRepFloats) rep *= 2;
+        stats_used -= tab.rep[ci] * 2 * c.cout;
+        tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
+        g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
+      }
+      if (st_conv3x3_s2(&g, stream)) return 1;
+      log_launch("conv3x3_s2", "3x3 stride 2", c.cin, c.cout, 3, 2, hin, win, 2.0 * B * d.Ho * d.Wo * 9.0 * c.cin * c.cout,
+                 ((double)B * hin * win * c.cin + (double)B * d.Ho * d.Wo * c.cout + 9.0 * c.cin * c.cout) * es);
     } else {
       if (st_conv(&d, stream)) return 1;
       const double rows_o = (double)B * d.Ho * d.Wo;
@@ -569,13 +596,15 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       // train: bn1 + relu ride in conv2's fill when the image-resident kernel takes conv2 (one pass over the tensor less)
       const ConvL& c2 = r->convs[b.c2];
       const ConvL& c3 = r->convs[b.c3];
-      const bool fuse1 = train && use_img && c2.ntw > 0 && st_conv3x3_img_supported(h, w, c2.cin, c2.cout) == c2.ntw;   // conv1 keeps the map size
+      const bool fuse1 = train && use_img && c2.ntw > 0 && c2.stride == 1 && st_conv3x3_img_supported(h, w, c2.cin, c2.cout) == c2.ntw;   // conv1 keeps the map size
       const bool c3_sums = train && use_img && c3.ntw > 0;       // conv3 on st_conv1x1_wreg: sums conv2's replicated statistics itself
       // conv2 on st_conv (the three stride-2 3x3s): its loader takes bn1 + relu too (igemm MODE 2, padding taps stay zero); it reads
       // replica 0 of conv1's statistics, so conv1's replicas are reduced by a launch (5 us against a 14 - 44 us pass over the tensor)
       static const bool xf_env = [] { const char* e = getenv("ST_CONV2_XF"); return !e || atoi(e) != 0; }();
       const bool fuse1x = xf_env && train && use_img && !fuse1 && c2.k == 3 && c2.cin % 64 == 0;
-      if (conv(b.c1, c1_in, h, w, narrow[0], nullptr, 1, &h1, &w1, bi == 0 ? stem_in : -1, !fuse1x, fz)) return 1;
+      // (the K-streaming stride-2 kernel sums conv1's statistics replicas itself: no reduction launch in front of it)
+      const bool c2_s2k = use_s2 && c2.k == 3 && c2.stride == 2 && c2.ntw > 0 && st_conv3x3_s2_supported(c2.cin, c2.cout) == c2.ntw;
+      if (conv(b.c1, c1_in, h, w, narrow[0], nullptr, 1, &h1, &w1, bi == 0 ? stem_in : -1, !fuse1x || c2_s2k, fz)) return 1;
       if (fz && tap(xin, h, w, r->convs[b.c1].cin)) return 1;      // the PREVIOUS block's output was formed by this conv1's loader
       if (train && !fuse1 && !fuse1x && bnact(b.c1, narrow[0], (long)B * h1 * w1, 1, nullptr, -1)) return 1;
       const bool fuse2_ = train && c3.cin % 64 == 0;              // conv3 applies bn2 + relu in its loader

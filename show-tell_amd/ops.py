@@ -261,6 +261,29 @@ def conv3x3_img(x, w_frag, N, stats=None, stats_replicas=0, scale=None, shift=No
     return out
 
 
+def conv3x3_s2_supported(Cin, N):
+    return int(lib().st_conv3x3_s2_supported(Cin, N))
+
+
+def conv3x3_s2(x, w_frag, N, stats=None, stats_replicas=0, scale=None, shift=None, relu=False, in_bn=None, out=None):
+    """K-streaming 3x3 stride-2 pad-1 conv (st_conv3x3_s2): x (B,H,W,C) bf16 NHWC, w_frag = pack_conv_weight_frag(w, conv3x3_s2_supported(C, N))."""
+    _dev(x, w_frag, stats, scale, shift, out)
+    B, H, W, Cc = x.shape
+    if x.dtype != torch.bfloat16:
+        raise _lib.ShowTellHipError("conv3x3_s2 is a bf16 kernel")
+    if out is None:
+        out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, N, device=x.device, dtype=torch.bfloat16)
+    d = Conv3x3ImgDesc(_p(x), _p(w_frag), _p(out), _p(stats), int(stats_replicas), _p(scale), _p(shift), int(relu),
+                       None, None, None, 0.0, 0.0, B, H, W, Cc, N, 0)
+    if in_bn is not None:
+        _dev(in_bn["stats"], in_bn["gamma"], in_bn["beta"])
+        d.in_stats, d.in_gamma, d.in_beta = in_bn["stats"].data_ptr(), in_bn["gamma"].data_ptr(), in_bn["beta"].data_ptr()
+        d.in_count, d.in_eps = float(in_bn["count"]), float(in_bn.get("eps", 1e-5))
+        d.in_stats_replicas = int(in_bn.get("replicas", 0))
+    check(lib().st_conv3x3_s2(C.byref(d), _stream()), "st_conv3x3_s2")
+    return out
+
+
 def conv1x1_wreg_supported(Cin, N):
     return int(lib().st_conv1x1_wreg_supported(Cin, N))
 

@@ -537,3 +537,50 @@ def test_conv_c3c1_eval_equals_astat_residual_then_kstream(shape):
     from showtell_amd import ShowTellHipError
     with pytest.raises(ShowTellHipError):
         ops.conv_c3c1(x2, w3a, ident, w1k, scale3=sc3, shift3=sh3)            # eval needs all four folded coefficient vectors
+
+
+# ---- st_conv3x3_s2: the stride-2 3x3 convs (B, H, W, C = N) -------------------------------------------------------------------------
+S2_CASES = [(2, 56, 56, 128), (3, 28, 28, 256), (5, 14, 14, 512), (1, 9, 7, 128), (2, 5, 5, 256), (1, 1, 1, 512), (3, 13, 15, 256)]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv3x3_s2_matches_conv2d_and_igemm(case):
+    """K-streaming stride-2 3x3 (odd and even maps, a single pixel): output vs F.conv2d and vs the implicit-GEMM kernel, statistics,
+    producer's BatchNorm + ReLU in the loader == the separate pass bit for bit (padding stays zero after the transform), eval epilogue."""
+    ops = _ops()
+    B, H, W, C = case
+    N = C
+    ntw = ops.conv3x3_s2_supported(C, N)
+    assert ntw > 0 and ops.conv3x3_s2_supported(64, 64) == 0
+    g = torch.Generator().manual_seed(B * H * W + C)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.1 + 0.15).bfloat16()
+    w = (torch.randn(N, C, 3, 3, generator=g) / np.sqrt(9 * C)).bfloat16().float()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 2, 1).permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda()
+    wf = ops.pack_conv_weight_frag(w.cuda(), ntw)
+    st = torch.zeros(4, 2 * N, device="cuda")
+    y = ops.conv3x3_s2(xd, wf, N, stats=st, stats_replicas=4)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    scale = ref.abs().max().item()
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.5e-2 * scale
+    y0 = ops.conv_nhwc(xd, ops.pack_conv_weight(w.cuda(), torch.bfloat16, k_order=1), 3, 3, 2, 1, k_order=1)
+    assert (y.float() - y0.float()).abs().max().item() <= 2.0 ** -6 * scale
+    r2 = ref.reshape(-1, N)
+    tot = st.sum(0).cpu().numpy()
+    np.testing.assert_allclose(tot[:N], r2.sum(0).numpy(), rtol=2e-3, atol=2e-3 * scale * np.sqrt(r2.shape[0]))
+    np.testing.assert_allclose(tot[N:], (r2 * r2).sum(0).numpy(), rtol=2e-3, atol=1e-4)
+    # producer's BatchNorm + ReLU in the loader
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    x2 = xd.float().reshape(-1, C)
+    stats = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).contiguous()
+    n = float(B * H * W)
+    y_sep = ops.conv3x3_s2(ops.bn_act(xd, gam, bet, stats=stats, count=n, relu=True), wf, N)
+    rep = torch.zeros(3, 2 * C, device="cuda"); rep[1] = stats
+    y_fused = ops.conv3x3_s2(xd, wf, N, in_bn=dict(stats=rep, gamma=gam, beta=bet, count=n, replicas=3))
+    assert torch.equal(y_sep, y_fused)
+    # eval-mode epilogue
+    sc, sh = (torch.rand(N, generator=g) + 0.5), torch.randn(N, generator=g) * 0.3
+    y2 = ops.conv3x3_s2(xd, wf, N, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    ref2 = F.relu(ref * sc + sh)
+    assert (y2.float().cpu() - ref2).abs().max().item() <= 1.5e-2 * max(ref2.abs().max().item(), 1e-3)
