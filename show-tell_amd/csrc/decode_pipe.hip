@@ -5,7 +5,7 @@
 // kernel boundary (43.9 us per step at B = 128, 0.078 of the HBM roofline), and a persistent kernel whose stages synchronise ALL 256
 // workgroups pays the same in cross-XCD hand-offs (tools/persistent_probe.hip: 45.3 us).  What does work (tools/xcd_pipeline_probe.hip:
 // 18.8 - 19.5 us per step) is to give every stage its own XCD and to cut the batch into independent CHAINS of 32 sequences:
-//   * XCD l < L holds GRU layer l: 32 workgroups x 16 hidden units; a workgroup's 48 gate rows of W_ih and W_hh (96 KB) stay in the
+//   * XCD l < L holds GRU (or LSTM: 4 gates, cell state in the workgroup's LDS) layer l: 32 workgroups x 16 hidden units; a workgroup's 48 gate rows of W_ih and W_hh (96 KB) stay in the
 //     registers of its four waves (K split four ways, exactly the K partition of rnn_gemm_kernel) for the whole decode;
 //   * XCDs L .. 7 hold the vocabulary projection: (8 - L) x 32 workgroups x <= 128 entries, weights in registers (full K per wave,
 //     one accumulator chain per 16-entry tile: the summation order of vocab_argmax_lds_kernel);
@@ -65,12 +65,16 @@ __device__ __forceinline__ bool wait_count(const unsigned* c, unsigned want, uns
   return *abort_flag == 0;
 }
 
+// NG = 3: GRU (gate rows r, z, n); NG = 4: LSTM (i, f, g, o; the cell state of a workgroup's own 16 units never leaves its LDS)
+template <int NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void decode_pipe_kernel(PipeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS: [0, 32 x PIXB) activation tile | reduction buffer [4 waves][2 tiles][3 gates][64] f32x4 | wbest [4][32] u64 | flags
+  // LDS: [0, 32 x PIXB) activation tile | reduction buffer [4 waves][2 tiles][NG gates][64] f32x4 | wbest [4][32] u64 | flags |
+  //      LSTM: cell state [8 chains][2 tiles][64 lanes] f32x4 (bf16-rounded values, as the launch chain stores c)
   f32x4* red = reinterpret_cast<f32x4*>(smem + CR * PIXB);
-  unsigned long long* wbest = reinterpret_cast<unsigned long long*>(smem + CR * PIXB + 4 * 2 * 3 * 64 * 16);
-  int* flags = reinterpret_cast<int*>(smem + CR * PIXB + 4 * 2 * 3 * 64 * 16 + 4 * CR * 8);
+  unsigned long long* wbest = reinterpret_cast<unsigned long long*>(smem + CR * PIXB + 4 * 2 * 4 * 64 * 16);
+  int* flags = reinterpret_cast<int*>(smem + CR * PIXB + 4 * 2 * 4 * 64 * 16 + 4 * CR * 8);
+  f32x4* cstate = reinterpret_cast<f32x4*>(smem + CR * PIXB + 4 * 2 * 4 * 64 * 16 + 4 * CR * 8 + 64);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -106,9 +110,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ================================ GRU layer l = xcc: hidden units [16 li, 16 li + 16) =================================================
     const int l = xcc;
     // weights in registers: wave w holds K-steps 4w .. 4w + 3 of both halves for the 3 gates (rnn_gemm_kernel's K slice `wid`)
-    u32x4 wx[3][4], wh[3][4];
+    u32x4 wx[NG][4], wh[NG][4];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const size_t off = (size_t)(g * PH + 16 * li + r16) * PH + ((wid * 4 + kk) * 4 + q4) * 8;
@@ -116,16 +120,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         wh[g][kk] = *reinterpret_cast<const u32x4*>(a.w_hh[l] + off);
       }
     // biases of this lane's units 16 li + 4 q4 + e (epilogue lanes: waves 0 and 1, one 16-row tile each)
-    float bi_[3][4], bh_[3][4];
+    float bi_[NG][4], bh_[NG][4];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bi_[g][e] = a.b_ih[l][g * PH + 16 * li + 4 * q4 + e]; bh_[g][e] = a.b_hh[l][g * PH + 16 * li + 4 * q4 + e]; }
 
     for (int t = 0; t < a.steps; ++t) {
       for (int c = 0; c < nch; ++c) {
         const int r0 = c * CR;
-        float gh[3][4], hp[4] = {0.f, 0.f, 0.f, 0.f};
+        float gh[NG][4], hp[4] = {0.f, 0.f, 0.f, 0.f};
         // ---- recurrent half, OFF the token chain: gh = W_hh h_l(t-1) + b_hh (t = 0: h = 0) --------------------------------------------
         if (t > 0) {
           if (!wait_count(cnt_of(t - 1, l, c), 32u, err, wid, lane, abort_flag)) return;   // (this layer's own previous step: all 32 slices)
@@ -135,15 +139,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int i = 0; i < 8; ++i) rowp[i] = hb + (size_t)((tid >> 6) + 4 * i) * PH;
           stage_rows(rowp);
           __syncthreads();
-          f32x4 acc[2][3];
+          f32x4 acc[2][NG];
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < NG; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
               for (int i = 0; i < 2; ++i) {
                 const u32x4 fa = *reinterpret_cast<const u32x4*>(smem + (i * 16 + r16) * PIXB + ((wid * 4 + kk) * 4 + q4) * 16);
@@ -157,14 +161,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) red[((wid * 2 + i) * 3 + g) * 64 + lane] = acc[i][g];
+            for (int g = 0; g < NG; ++g) red[((wid * 2 + i) * NG + g) * 64 + lane] = acc[i][g];
           __syncthreads();
           if (wid < 2) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-              f32x4 s = red[((0 * 2 + wid) * 3 + g) * 64 + lane];
+            for (int g = 0; g < NG; ++g) {
+              f32x4 s = red[((0 * 2 + wid) * NG + g) * 64 + lane];
 #pragma unroll
-              for (int w = 1; w < 4; ++w) s += red[((w * 2 + wid) * 3 + g) * 64 + lane];
+              for (int w = 1; w < 4; ++w) s += red[((w * 2 + wid) * NG + g) * 64 + lane];
 #pragma unroll
               for (int e = 0; e < 4; ++e) gh[g][e] = s[e] + bh_[g][e];
             }
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           __syncthreads();                             // the tile and the reduction buffer are free again
         } else {
 #pragma unroll
-          for (int g = 0; g < 3; ++g)
+          for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) gh[g][e] = 0.f + bh_[g][e];
         }
@@ -205,15 +209,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __syncthreads();
         {
-          f32x4 acc[2][3];
+          f32x4 acc[2][NG];
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < NG; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
               for (int i = 0; i < 2; ++i) {
                 const u32x4 fa = *reinterpret_cast<const u32x4*>(smem + (i * 16 + r16) * PIXB + ((wid * 4 + kk) * 4 + q4) * 16);
@@ -222,22 +226,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) red[((wid * 2 + i) * 3 + g) * 64 + lane] = acc[i][g];
+            for (int g = 0; g < NG; ++g) red[((wid * 2 + i) * NG + g) * 64 + lane] = acc[i][g];
         }
         __syncthreads();
         if (wid < 2) {
-          float xg[3][4];
+          float xg[NG][4];
 #pragma unroll
-          for (int g = 0; g < 3; ++g) {
-            f32x4 s = red[((0 * 2 + wid) * 3 + g) * 64 + lane];
+          for (int g = 0; g < NG; ++g) {
+            f32x4 s = red[((0 * 2 + wid) * NG + g) * 64 + lane];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) s += red[((w * 2 + wid) * 3 + g) * 64 + lane];
+            for (int w = 1; w < 4; ++w) s += red[((w * 2 + wid) * NG + g) * 64 + lane];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xg[g][e] = s[e] + bi_[g][e];
+            for (int e = 0; e < 4; ++e) xg[g][e] = NG == 3 ? s[e] + bi_[g][e] : s[e];      // LSTM: the raw sums (bias added in its own order below)
           }
           float hn[4];
+          if constexpr (NG == 3) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { float r_, z_, n_; hn[e] = st_gru_unit(xg[0][e], xg[1][e], xg[2][e], gh[0][e], gh[1][e], gh[2][e], hp[e], r_, z_, n_); }
+            for (int e = 0; e < 4; ++e) { float r_, z_, n_; hn[e] = st_gru_unit(xg[0][e], xg[1][e], xg[2][e], gh[0][e], gh[1][e], gh[2][e], hp[e], r_, z_, n_); }
+          } else {
+            // rnn_gemm_kernel's LSTM epilogue, split form: pre = ((0 + gh) + input-half sums) + b_ih; c is stored (and read back) in bf16
+            f32x4 cp = t > 0 ? cstate[(c * 2 + wid) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 cnew;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float pre[4], ig, fg, gg, og, cn;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) pre[g] = ((0.f + gh[g][e]) + xg[g][e]) + bi_[g][e];
+              hn[e] = st_lstm_unit(pre[0], pre[1], pre[2], pre[3], cp[e], ig, fg, gg, og, cn);
+              cnew[e] = cn;
+            }
+            const u32x2 cb = u32x2{pack_bf16x2(cnew[0], cnew[1]), pack_bf16x2(cnew[2], cnew[3])};
+            cstate[(c * 2 + wid) * 64 + lane] = f32x4{__uint_as_float(cb[0] << 16), __uint_as_float(cb[0] & 0xffff0000u),
+                                                     __uint_as_float(cb[1] << 16), __uint_as_float(cb[1] & 0xffff0000u)};
+          }
           const u32x2 o = u32x2{pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3])};
           bf16_t* dst = act_buf(t, l, c) + (size_t)(wid * 16 + r16) * PH + 16 * li + 4 * q4;
           asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(o) : "memory");
@@ -356,7 +377,7 @@ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // bytes the pipelined decoder needs behind the launch chain's workspace (0: this configuration stays on the launch chain)
 size_t rnn_greedy_pipe_bytes(const st_rnn_params* p, int B, int steps) {
-  if (!p || p->cell != ST_CELL_GRU || p->dtype != ST_BF16 || p->L < 1 || p->L > MAXL || p->H != PH || p->E != PH || p->in0 != PH) return 0;
+  if (!p || (p->cell != ST_CELL_GRU && p->cell != ST_CELL_LSTM) || p->dtype != ST_BF16 || p->L < 1 || p->L > MAXL || p->H != PH || p->E != PH || p->in0 != PH) return 0;
   if (B < 1 || B > 256 || steps < 1 || steps > 64) return 0;
   const int nvw = (8 - p->L) * 32, ntile = (p->V + 15) / 16, tpw = (ntile + nvw - 1) / nvw;
   if (tpw > 8) return 0;
@@ -395,10 +416,12 @@ int rnn_greedy_pipe(const st_rnn_params* p, const void* feat, int B, int steps, 
   if (hipMemsetAsync(zero0, 0, (size_t)(w - zero0), st) != hipSuccess) { st_set_error("rnn_greedy_pipe: memset failed"); return 1; }
   static int attr_set[64] = {};
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_pipe_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_pipe_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
     attr_set[dev] = 1;
   }
-  hipLaunchKernelGGL(decode_pipe_kernel, dim3(256), dim3(256), PIPE_LDS, st, a);
+  if (p->cell == ST_CELL_GRU) hipLaunchKernelGGL(decode_pipe_kernel<3>, dim3(256), dim3(256), PIPE_LDS, st, a);
+  else hipLaunchKernelGGL(decode_pipe_kernel<4>, dim3(256), dim3(256), PIPE_LDS, st, a);
   ST_LAUNCH_CHECK();
   unsigned flag = 0;
   if (hipMemcpyAsync(&flag, a.ticket + 8, sizeof(flag), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {

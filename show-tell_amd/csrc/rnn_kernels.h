@@ -52,6 +52,13 @@ __device__ __forceinline__ float st_gru_unit(float xr, float xz, float xn, float
   n = tanhf(__builtin_fmaf(r, hn, xn));
   return __builtin_fmaf(z, hprev, (1.f - z) * n);
 }
+// One LSTM unit (torch.nn.LSTM, gate order i, f, g, o; reference LSTM/rnn_lstm.py:30): pre* = W_i* x + b_i* + W_h* h + b_h*,
+//   c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c').  Same purpose as st_gru_unit: one definition, explicit FMA.
+__device__ __forceinline__ float st_lstm_unit(float pi, float pf, float pg, float po, float cprev, float& ig, float& fg, float& gg, float& og, float& cn) {
+  ig = st_sigm(pi); fg = st_sigm(pf); gg = tanhf(pg); og = st_sigm(po);
+  cn = __builtin_fmaf(fg, cprev, ig * gg);
+  return og * tanhf(cn);
+}
 #endif
 
 // the pipelined (layer-per-XCD) greedy decoder, csrc/decode_pipe.hip: bytes it needs behind the launch chain's workspace (0: the

@@ -288,11 +288,7 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnGemmBatch batch) {
       for (int e = 0; e < 4; ++e) pre[g][e] = (HAS_X ? sumX[g][e] : 0.f) + ex[g < NG ? g : 0][e] + sumH[g < NG ? g : 0][e] + eb[g < NG ? g : 0][e];
     float ig[4], fg[4], gg[4], og[4], cn[4], hnew[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ig[e] = sigm(pre[0][e]); fg[e] = sigm(pre[1][e]); gg[e] = tanhf(pre[2][e]); og[e] = sigm(pre[3][e]);
-      cn[e] = fg[e] * cp[e] + ig[e] * gg[e];
-      hnew[e] = og[e] * tanhf(cn[e]);
-    }
+    for (int e = 0; e < 4; ++e) hnew[e] = st_lstm_unit(pre[0][e], pre[1][e], pre[2][e], pre[3][e], cp[e], ig[e], fg[e], gg[e], og[e], cn[e]);
     store4<T>(reinterpret_cast<T*>(a.hout) + (long)m * a.ldho + n, hnew);
     if (a.hout2) store4<T>(reinterpret_cast<T*>(a.hout2) + (long)m * a.ldho2 + n, hnew);
     store4<T>(reinterpret_cast<T*>(a.cout) + (long)m * a.ldho + n, cn);

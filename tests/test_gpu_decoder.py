@@ -244,17 +244,23 @@ def test_optimizers_match_torch(kind):
         assert torch.equal(q._st_shadow.float().cpu(), q.detach().bfloat16().float().cpu())
 
 
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
 @pytest.mark.parametrize("B,L,V", [(128, 5, 10000), (8, 5, 10000), (33, 5, 10000), (256, 5, 10000), (64, 3, 9000), (40, 1, 12000), (16, 5, 777)])
-def test_pipelined_greedy_decoder_equals_launch_chain(B, L, V, monkeypatch):
-    """rnn.py:37-58 at the BASELINE decoder shape (E = H = 512, bf16): the persistent layer-per-XCD decoder (csrc/decode_pipe.hip)
+def test_pipelined_greedy_decoder_equals_launch_chain(B, L, V, cell, monkeypatch):
+    """rnn.py:37-58 / LSTM/rnn_lstm.py:35-57 at the BASELINE decoder shape (E = H = 512, bf16): the persistent layer-per-XCD decoder (csrc/decode_pipe.hip)
     must return the launch chain's token ids bit for bit -- same MFMA order, same gate function, same arg-max keys -- for full and
     ragged chains (B not a multiple of 32), fewer layers (more vocabulary XCDs) and other vocabulary sizes; and the fp32 / oracle
     agreement the launch chain is tested for carries over."""
     from showtell_amd.rnn import RNN
+    from showtell_amd.rnn_lstm import RNN as RNN_LSTM
     E = H = 512
-    sd = R.init_decoder_params(E, H, V, L, "gru", seed=11 + B)
+    sd = R.init_decoder_params(E, H, V, L, cell, seed=11 + B)
     sd["linear.weight"] *= 6.0
-    m = RNN(E, H, V, L, dtype=torch.bfloat16); m.load_state_dict(sd); m = m.cuda().eval()
+    if cell == "lstm":        # a default-initialised LSTM stack decodes to one constant token: give its gates some swing
+        for k in sd:
+            if k.startswith("unit.weight"):
+                sd[k] = sd[k] * 5.0
+    m = (RNN if cell == "gru" else RNN_LSTM)(E, H, V, L, dtype=torch.bfloat16); m.load_state_dict(sd); m = m.cuda().eval()
     feat = torch.randn(B, E, generator=torch.Generator().manual_seed(B)).cuda()
     monkeypatch.setenv("ST_DECODE_PIPE", "0")
     ids_chain = m.sentence_index(feat)
