@@ -278,7 +278,9 @@ def main():
         names[23] = "conv3x3s2_kstream_kernel (the three stride-2 3x3 convs, K-streaming implicit GEMM, csrc/conv_s2.hip)"
         prefixes[23] = ("conv3x3s2_kstream_kernel<",)
         names[22] = "conv_c3c1_kernel (14x14 Bottlenecks: conv3 256->1024 + block end + next conv1 1024->256 in one kernel, csrc/conv_c3c1.hip)"
-        prefixes[22] = ("conv_c3c1_kernel<true>",)      # the train-mode form (the eval form appears in `secondary`'s config-5 encoder)
+        prefixes[22] = ("conv_c3c1_kernel<256,1024,256,7,1,true>", "conv_c3c1_kernel<true>")      # the train-mode form (the eval form appears in `secondary`'s config-5 encoder)
+        names[24] = "conv_c3c1_kernel<128,512,128> (28x28 Bottlenecks: conv3 128->512 + block end + next conv1 512->128, HBM-bound, csrc/conv_c3c1.hip)"
+        prefixes[24] = ("conv_c3c1_kernel<128,512,128,5,2,true>",)
         v = max(range(32), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12 if ms[v] > 0 else 0.0
         tot_ms, tot_fl = sum(ms), sum(fl)

@@ -180,18 +180,20 @@ typedef struct {
  * ntw = N / 64 -- what st_conv1x1_wreg_supported returns for these layers today; a caller that packs another ntw gets wrong channels. */
 int st_conv_b2b_supported(int C1, int C2, int N);
 int st_conv_b2b(const st_conv_b2b_desc* d, void* stream);
-/* conv3 of a 14 x 14 Bottleneck (C1 = 256 -> C2 = 1024), the block's end, and conv1 of the NEXT block (C2 -> N = 256) in one kernel
- * (csrc/conv_c3c1.hip; torchvision Bottleneck.forward twice over, reference cnn.py:46):
+/* conv3 of a 14 x 14 Bottleneck (C1 = 256 -> C2 = 1024) or a 28 x 28 one (128 -> 512), the block's end, and conv1 of the NEXT block
+ * (C2 -> N = C1) in one kernel (csrc/conv_c3c1.hip; torchvision Bottleneck.forward twice over, reference cnn.py:46):
  *   x_out = relu(bn3(conv3(a2)) + identity),   y = conv1_next(x_out)
  * conv3's output channels are conv1's K dimension: each finished 128-channel chunk of x is stored once AND is one K-slab of conv1
- * (through LDS); x is never read back.  Replaces st_conv1x1_astat + st_bn_act + st_conv1x1_kstream.
+ * (through LDS); x is never read back.  Replaces st_conv1x1_astat + st_bn_act + st_conv1x1_kstream (28 x 28: st_conv1x1_wreg +
+ * st_bn_act + st_conv1x1_wreg).
  *   train (bn3_stats given): a2 = relu(batchnorm(x2; bn2_*)) (bn2_stats NULL: x2 is already normalised); bn3 from the batch statistics of
- *     conv3's output, which a STATISTICS-ONLY st_conv1x1_astat call (y == NULL) over the same x2 / w3_frag produces first; `stats` receives
+ *     conv3's output, which a STATISTICS-ONLY st_conv1x1_astat (28 x 28: st_conv1x1_wreg) call (y == NULL) over the same x2 / w3_frag
+ *     produces first; `stats` receives
  *     [sum | sumsq] of y.  x_out and y are bit-identical to the three-kernel path.
  *   eval (scale3 / shift3 / scale1 / shift1 given, no statistics): a2 = x2, x_out = relu(conv3 * scale3 + shift3 + identity),
  *     y = conv1(x_out) * scale1 + shift1 (ReLU if relu1).
- * x2: [rows][256], identity / x_out: [rows][1024], y: [rows][256], all bf16.  w3_frag: st_pack_conv_weight_frag(ntw = 2) (the layout
- * st_conv1x1_astat uses), w1_frag: ntw = 4 (st_conv1x1_kstream's). */
+ * x2: [rows][C1], identity / x_out: [rows][C2], y: [rows][N], all bf16.  w3_frag: st_pack_conv_weight_frag(ntw = 2) (the layout
+ * st_conv1x1_astat / st_conv1x1_wreg use for conv3), w1_frag: ntw = N / 64 (st_conv1x1_kstream's | st_conv1x1_wreg's for that conv1). */
 typedef struct {
   const void* x2; const void* w3_frag; const void* identity; void* x_out; const void* w1_frag; void* y;
   float* stats; int stats_replicas;
@@ -286,6 +288,8 @@ typedef struct {
 } st_stem_conv_pool_desc;
 int st_stem_conv_pool(const st_stem_conv_pool_desc* d, void* stream);
 int st_stem_weight_frag(const void* w_s2d, void* out, void* stream);
+/* == st_stem_weight_frag(st_stem_weight_s2d(w_packed, bf16, Cpad)) in one launch (what st_resnet_forward runs per forward) */
+int st_stem_weight_frag_packed(const void* w_packed, int Cpad, void* out, void* stream);
 /* global average pool NHWC -> [B][C] (adaptive avgpool, cnn.py:34) */
 int st_global_avgpool(const void* x, void* y, int dtype, int out_dtype, int B, int HW, int C, void* stream);
 

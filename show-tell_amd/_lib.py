@@ -141,6 +141,7 @@ _SIGS = {
     "st_nchw_to_s2d16": ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_stem_weight_s2d": ([c_p, c_p, c_i, c_i, c_p], c_i),
     "st_stem_weight_frag": ([c_p, c_p, c_p], c_i),
+    "st_stem_weight_frag_packed": ([c_p, c_i, c_p, c_p], c_i),
     "st_stem_conv_pool": ([C.POINTER(StemConvPoolDesc), c_p], c_i),
     "st_nhwc_to_ncp_f32": ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     "st_maxpool3x3s2": ([c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),

@@ -27,6 +27,11 @@
 //             with E(c) -- the epilogue of A(c): identity (requested a chunk ahead), bn3, ReLU, bf16, x_out store, slab write --
 //             spread two 16-row tiles per K-step under B's MFMAs
 //   end       acc1 -> statistics | scale / shift / ReLU -> y
+//
+// The 28 x 28 Bottlenecks (128 -> 512 -> 128) run the same body with 4 chunks and 80-row workgroups, two per CU (template
+// parameters below; the separate path there is st_conv1x1_wreg -> st_bn_act | st_conv_b2b -> st_conv1x1_wreg, and the bit-identity
+// holds against it).  The gain is small there (62 - 77 us in the forward against 46 + 31 for the two launches it replaces): at
+// 257 MB per launch the kernel is HBM time (43 us at 6 TB/s), not boundary time.
 #include "common.h"
 #include "prof.h"
 
@@ -76,19 +81,24 @@ __device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t rs, int voff, in
   __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, coff, ST_STORE_POLICY == 1 ? 16 : 0);
 }
 
-constexpr int K3 = 256, N3 = 1024, N1 = 256;                         // conv3: K3 -> N3, conv1: N3 -> N1
-constexpr int TM = 7, BM = 16 * TM;                                  // 112 rows per workgroup
-constexpr int PIX3 = 2 * K3 + 32;                                    // padded LDS row of the conv3 input (bytes)
 constexpr int CW = 128, PIXS = 2 * CW + 32;                          // chunk width (conv3 output channels = conv1 K-slab), padded slab row
-constexpr int NCHUNK = N3 / CW;                                      // 8
-constexpr int KS3 = K3 / 32, KSB = CW / 32, KS1 = N3 / 32;           // K-steps: conv3 per chunk (8), conv1 per slab (4), conv1 in all (32)
-constexpr int NTW3 = 2, NTW1 = 4;                                    // 16-channel tiles per wave: conv3 (32 of a chunk's 128), conv1 (64 of 256)
-constexpr int WR3 = 6, WR1 = 4;                                      // filter rings (K-steps in flight)
-constexpr int A2_BYTES = BM * PIX3, SLAB_BYTES = BM * PIXS;
-constexpr int C3_LDS = A2_BYTES + 2 * SLAB_BYTES + 2 * N3 * 4 + 2 * K3 * 4;
+constexpr int KSB = CW / 32;                                         // conv1 K-steps per slab (4)
+constexpr int NTW3 = 2;                                              // conv3: 16-channel tiles per wave (32 of a chunk's 128)
+template <int K3, int N3, int N1, int TM> constexpr int c3_lds() { return 16 * TM * (2 * K3 + 32) + 2 * 16 * TM * PIXS + 2 * N3 * 4 + 2 * K3 * 4; }
 
-template <bool TRAIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_c3c1_kernel(C3Args a) {
+// (K3, N3, N1): conv3 K3 -> N3, next conv1 N3 -> N1.  (256, 1024, 256): the layer3 blocks; (128, 512, 128): the layer2 blocks.
+// TM: 16-row tiles per workgroup; WPE: workgroups per CU the register budget is cut for (waves per SIMD)
+template <int K3, int N3, int N1, int TM, int WPE, bool TRAIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_c3c1_kernel(C3Args a) {
+  constexpr int BM = 16 * TM, SLAB_BYTES = BM * PIXS;                // rows per workgroup
+  constexpr int WR3 = WPE == 1 ? 6 : 4, WR1 = 4;                     // filter rings (K-steps in flight)
+  constexpr int PIX3 = 2 * K3 + 32;                                  // padded LDS row of the conv3 input (bytes)
+  constexpr int NCHUNK = N3 / CW;                                    // 8 | 4
+  constexpr int KS3 = K3 / 32, KS1 = N3 / 32;                        // K-steps: conv3 per chunk, conv1 in all
+  constexpr int NTW1 = N1 / 64;                                      // conv1: 16-channel tiles per wave (N1 / 4 channels per wave)
+  constexpr int A2_BYTES = BM * PIX3;
+  constexpr int NB3 = N3 / 256;                                      // bn3 channels per thread in the prologue (4 | 2)
+  static_assert(K3 <= 256 && N3 % 256 == 0 && N1 % 128 == 0 && KS3 >= 4, "geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slab = smem + A2_BYTES;
   float* coef3 = reinterpret_cast<float*>(smem + A2_BYTES + 2 * SLAB_BYTES);     // [scale(N3) | shift(N3)]
@@ -116,7 +126,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---- coefficient inputs FIRST: they head the in-order load queue, so consuming them (below, after every tile / filter load has been
   // issued) waits for them alone.  Train: the first four replicas of bn3's statistics for this thread's four channels and of bn2's for
   // its one channel (K3 == blockDim), gamma / beta; all unconditional (a NULL bn2 reads bn3's arrays and is ignored).
-  float sa[4][4], sb[4][4], gg[4], bb[4], s2a[4], s2b[4], g2v = 1.f, b2v = 0.f;
+  float sa[NB3][4], sb[NB3][4], gg[NB3], bb[NB3], s2a[4], s2b[4], g2v = 1.f, b2v = 0.f;
+  const int c2i = tid % K3;                                          // this thread's bn2 channel (K3 <= blockDim)
   if constexpr (TRAIN) {
     const float* s2p = a.s2 ? a.s2 : a.s3;
     const float* g2p = a.s2 ? a.g2 : a.g3;
@@ -126,15 +137,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int q = 0; q < 4; ++q) {
       const int r3 = q < a.s3rep ? q : a.s3rep - 1, r2 = q < rep2 ? q : rep2 - 1;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { sa[k][q] = a.s3[(size_t)r3 * 2 * N3 + tid + 256 * k]; sb[k][q] = a.s3[(size_t)r3 * 2 * N3 + N3 + tid + 256 * k]; }
-      s2a[q] = s2p[(size_t)r2 * 2 * K3 + tid]; s2b[q] = s2p[(size_t)r2 * 2 * K3 + K3 + tid];
+      for (int k = 0; k < NB3; ++k) { sa[k][q] = a.s3[(size_t)r3 * 2 * N3 + tid + 256 * k]; sb[k][q] = a.s3[(size_t)r3 * 2 * N3 + N3 + tid + 256 * k]; }
+      s2a[q] = s2p[(size_t)r2 * 2 * K3 + c2i]; s2b[q] = s2p[(size_t)r2 * 2 * K3 + K3 + c2i];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { gg[k] = a.g3[tid + 256 * k]; bb[k] = a.b3[tid + 256 * k]; }
-    g2v = g2p[tid]; b2v = b2p[tid];
+    for (int k = 0; k < NB3; ++k) { gg[k] = a.g3[tid + 256 * k]; bb[k] = a.b3[tid + 256 * k]; }
+    g2v = g2p[c2i]; b2v = b2p[c2i];
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { gg[k] = a.sc3[tid + 256 * k]; bb[k] = a.sh3[tid + 256 * k]; }
+    for (int k = 0; k < NB3; ++k) { gg[k] = a.sc3[tid + 256 * k]; bb[k] = a.sh3[tid + 256 * k]; }
   }
 
   u32x4 wq3[WR3][NTW3], wq1[WR1][NTW1];
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float inv = 1.0f / a.count;
       {   // bn3 scale / shift of all 1024 channels (four per thread), replicas added in replica order (as every other consumer does)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NB3; ++k) {
           float sm = 0.f, sq = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) { sm += q < a.s3rep ? sa[k][q] : 0.f; sq += q < a.s3rep ? sb[k][q] : 0.f; }
@@ -190,8 +201,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           float sm = 0.f, sq = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) { sm += q < a.s2rep ? s2a[q] : 0.f; sq += q < a.s2rep ? s2b[q] : 0.f; }
-          for (int r = 4; r < a.s2rep; ++r) { sm += a.s2[(size_t)r * 2 * K3 + tid]; sq += a.s2[(size_t)r * 2 * K3 + K3 + tid]; }
-          bn_scale_shift(sm, sq, inv, g2v, b2v, a.eps, coef2[tid], coef2[K3 + tid]);
+          for (int r = 4; r < a.s2rep; ++r) { sm += a.s2[(size_t)r * 2 * K3 + c2i]; sq += a.s2[(size_t)r * 2 * K3 + K3 + c2i]; }
+          if (tid < K3) bn_scale_shift(sm, sq, inv, g2v, b2v, a.eps, coef2[c2i], coef2[K3 + c2i]);
         }
         __syncthreads();
         float sc[8], sh[8];
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { coef3[tid + 256 * k] = gg[k]; coef3[N3 + tid + 256 * k] = bb[k]; }
+      for (int k = 0; k < NB3; ++k) { coef3[tid + 256 * k] = gg[k]; coef3[N3 + tid + 256 * k] = bb[k]; }
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i) *reinterpret_cast<u32x4*>(smem + (lrow + i * RPP) * PIX3 + cch * 16) = v[i];
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int j = 0; j < NTW1; ++j) wq1[h % WR1][j] = wfrag1(h + WR1, j);
         }
         if (c < NCHUNK) {
-          tile_e(c, 2 * kk);
+          if (2 * kk < TM) tile_e(c, 2 * kk);
           if (2 * kk + 1 < TM) tile_e(c, 2 * kk + 1);
           // E's VALU stream (accumulator reads, bn3, ReLU, packing: ~45 instructions per tile) does not depend on B's MFMAs: ask the
           // scheduler to issue it BETWEEN them (an MFMA holds the issue port for 8 of its 16 cycles: ~2 other instructions fit per MFMA
@@ -395,18 +406,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef C3_STAMP
 }
 
-template <bool TRAIN>
+template <int K3, int N3, int N1, int TM, int WPE, bool TRAIN>
 int launch_c3c1(C3Args& a, hipStream_t st, double flops) {
-  static_assert(C3_LDS <= 160 * 1024, "LDS");
+  constexpr int lds = c3_lds<K3, N3, N1, TM>(), BM = 16 * TM;
+  static_assert(lds * WPE <= 160 * 1024, "LDS");
   static int attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c3c1_kernel<TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c3c1_kernel<K3, N3, N1, TM, WPE, TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
-  StProfScope prof(22, flops, st);
-  hipLaunchKernelGGL((conv_c3c1_kernel<TRAIN>), dim3((a.M + BM - 1) / BM), dim3(256), C3_LDS, st, a);
+  StProfScope prof(K3 == 256 ? 22 : 24, flops, st);
+  hipLaunchKernelGGL((conv_c3c1_kernel<K3, N3, N1, TM, WPE, TRAIN>), dim3((a.M + BM - 1) / BM), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
@@ -414,12 +426,14 @@ int launch_c3c1(C3Args& a, hipStream_t st, double flops) {
 
 }  // namespace
 
-extern "C" int st_conv_c3c1_supported(int C1, int C2, int N) { return (C1 == K3 && C2 == N3 && N == N1) ? 1 : 0; }
+extern "C" int st_conv_c3c1_supported(int C1, int C2, int N) {
+  return ((C1 == 256 && C2 == 1024 && N == 256) || (C1 == 128 && C2 == 512 && N == 128)) ? 1 : 0;
+}
 
 extern "C" int st_conv_c3c1(const st_conv_c3c1_desc* d, void* stream) {
   ST_CHECK(d && d->x2 && d->w3_frag && d->identity && d->x_out && d->w1_frag && d->y, "st_conv_c3c1: null pointer");
   ST_CHECK(st_conv_c3c1_supported(d->C1, d->C2, d->N), "st_conv_c3c1: unsupported geometry %d -> %d -> %d", d->C1, d->C2, d->N);
-  ST_CHECK(d->rows > 0 && d->rows * (long)N3 * 2 < (1L << 31), "st_conv_c3c1: bad row count %ld", d->rows);
+  ST_CHECK(d->rows > 0 && d->rows * (long)d->C2 * 2 < (1L << 31), "st_conv_c3c1: bad row count %ld", d->rows);
   ST_CHECK(d->x_out != d->identity && d->x_out != d->x2 && d->y != d->x2, "st_conv_c3c1: outputs must not alias inputs");
   const bool train = d->bn3_stats != nullptr;
   if (train) {
@@ -439,6 +453,12 @@ extern "C" int st_conv_c3c1(const st_conv_c3c1_desc* d, void* stream) {
   a.sc3 = d->scale3; a.sh3 = d->shift3; a.sc1 = d->scale1; a.sh1 = d->shift1; a.relu1 = d->relu1;
   a.count = d->count; a.eps = d->eps; a.M = (int)d->rows; a.stamps = st_debug_stamps_ptr();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const double flops = 2.0 * (double)d->rows * ((double)K3 * N3 + (double)N3 * N1);
-  return train ? launch_c3c1<true>(a, st, flops) : launch_c3c1<false>(a, st, flops);
+  const double flops = 2.0 * (double)d->rows * ((double)d->C1 * d->C2 + (double)d->C2 * d->N);
+  if (d->C1 == 256) return train ? launch_c3c1<256, 1024, 256, 7, 1, true>(a, st, flops) : launch_c3c1<256, 1024, 256, 7, 1, false>(a, st, flops);
+  // 28 x 28: 80-row workgroups, two per CU (74 KB of LDS, <= 256 registers): one workgroup's fill / prologue runs under the other's
+  // walk, and 100352 rows make 1255 workgroups = 2.45 rounds of 512 slots.  Measured at B = 128 (tools/time_c3c1.py, train | eval):
+  // (TM 7, 1 per CU) 80 | 74 us, (4, 2) 80 | 74 (3.06 rounds), (3, 3) 93 | 110 (spills), (5, 2) 67 | 64.  ST_C3C1_L2=7: the (7, 1) form
+  static const int l2form = [] { const char* e = getenv("ST_C3C1_L2"); return e ? atoi(e) : 5; }();
+  if (l2form == 7) return train ? launch_c3c1<128, 512, 128, 7, 1, true>(a, st, flops) : launch_c3c1<128, 512, 128, 7, 1, false>(a, st, flops);
+  return train ? launch_c3c1<128, 512, 128, 5, 2, true>(a, st, flops) : launch_c3c1<128, 512, 128, 5, 2, false>(a, st, flops);
 }

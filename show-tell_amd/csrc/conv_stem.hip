@@ -256,7 +256,32 @@ __global__ void stem_weight_frag_kernel(const bf16_t* __restrict__ w, bf16_t* __
   out[o] = w[ch * 256 + k];
 }
 
+// the same operands straight from the packed [64][7][7][Cpad] filters: st_stem_weight_s2d's index map ([64][4][4][16]: tap (i, j), channel
+// (dy * 2 + dx) * 3 + c <- the 7 x 7 weight at (2 i + dy - 1, 2 j + dx - 1), zero outside) composed with the permutation above --
+// one launch per forward instead of two
+__global__ void stem_weight_frag_packed_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int Cpad) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;          // 0 .. 16383
+  const int j8 = o & 7, ln = (o >> 3) & 63, ks = (o >> 9) & 7, T = o >> 12;
+  const int r = ln & 15, n = 16 * (r >> 2) + 4 * T + (r & 3), t = 32 * ks + 8 * (ln >> 4) + j8;
+  const int i = t >> 6, j = (t >> 4) & 3, ch = t & 15;
+  bf16_t v = from_f32<bf16_t>(0.f);
+  if (ch < 12) {
+    const int blk = ch / 3, c = ch - blk * 3, dy = blk >> 1, dx = blk & 1;
+    const int ky = 2 * i + dy - 1, kx = 2 * j + dx - 1;
+    if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) v = w[((n * 7 + ky) * 7 + kx) * Cpad + c];
+  }
+  out[o] = v;
+}
+
 }  // namespace
+
+extern "C" int st_stem_weight_frag_packed(const void* w_packed, int Cpad, void* out, void* stream) {
+  ST_CHECK(w_packed && out && Cpad >= 3, "st_stem_weight_frag_packed: null pointer or Cpad=%d < 3", Cpad);
+  hipLaunchKernelGGL(stem_weight_frag_packed_kernel, dim3(64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const bf16_t*>(w_packed), reinterpret_cast<bf16_t*>(out), Cpad);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int st_stem_weight_frag(const void* w_s2d, void* out, void* stream) {
   ST_CHECK(w_s2d && out, "st_stem_weight_frag: null pointer");

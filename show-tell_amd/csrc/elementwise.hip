@@ -344,7 +344,19 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T
     float s[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) s[k] = 0.f;
-    for (int p = 0; p < HW; ++p) {
+    // seven loads in flight per thread, added in pixel order (a 7 x 7 map is seven batches)
+    constexpr int U = 7;
+    int p = 0;
+    for (; p + U <= HW; p += U) {
+      float v[U][N];
+#pragma unroll
+      for (int u = 0; u < U; ++u) Vec<T>::load(x + (b * HW + p + u) * C + c, v[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < N; ++k) s[k] += v[u][k];
+    }
+    for (; p < HW; ++p) {
       float v[N];
       Vec<T>::load(x + (b * HW + p) * C + c, v);
 #pragma unroll
@@ -578,12 +590,12 @@ extern "C" int st_global_avgpool(const void* x, void* y, int dtype, int out_dtyp
   ST_DT_CHECK(out_dtype, "st_global_avgpool");
   const int n = dtype == ST_BF16 ? 8 : 4;
   ST_CHECK(C % n == 0, "st_global_avgpool: C=%d must be a multiple of %d", C, n);
-  const int grid = grid_for((long)B * (C / n), 256);
+  const int grid = grid_for((long)B * (C / n), 64);   // one wave per block: 32 K threads at (128, 2048) reach every CU
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ST_BF16 && out_dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, HW, C);
-  else if (dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (float*)y, B, HW, C);
-  else if (out_dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)x, (bf16_t*)y, B, HW, C);
-  else hipLaunchKernelGGL((avgpool_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, B, HW, C);
+  if (dtype == ST_BF16 && out_dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<bf16_t, bf16_t>), dim3(grid), dim3(64), 0, st, (const bf16_t*)x, (bf16_t*)y, B, HW, C);
+  else if (dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<bf16_t, float>), dim3(grid), dim3(64), 0, st, (const bf16_t*)x, (float*)y, B, HW, C);
+  else if (out_dtype == ST_BF16) hipLaunchKernelGGL((avgpool_kernel<float, bf16_t>), dim3(grid), dim3(64), 0, st, (const float*)x, (bf16_t*)y, B, HW, C);
+  else hipLaunchKernelGGL((avgpool_kernel<float, float>), dim3(grid), dim3(64), 0, st, (const float*)x, (float*)y, B, HW, C);
   ST_LAUNCH_CHECK();
   return 0;
 }

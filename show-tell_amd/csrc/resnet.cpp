@@ -60,8 +60,11 @@ __global__ void bn_update_all_kernel(const float* __restrict__ stats, float* __r
   // stats holds, per layer l with channels [start_l, end_l): rep_l replicas of [sum(C_l) | sumsq(C_l)] at soff_l
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= total) return;
-  int l = 0;
-  while (l < t.n - 1 && c >= t.end[l]) ++l;
+  int l = 0, hi = t.n - 1;                 // first layer whose channel range ends past c (binary search: each probe is a dependent load)
+  while (l < hi) {
+    const int mid = (l + hi) >> 1;
+    if (c >= t.end[mid]) l = mid + 1; else hi = mid;
+  }
   const int start = l == 0 ? 0 : t.end[l - 1];
   const int C = t.end[l] - start;
   const float cnt = t.count[l];
@@ -298,7 +301,6 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   const bool s2d = stem_s2d(H, W);
   if (s2d) {
     if (st_nchw_to_s2d16(images_nchw, in8, dt, B, H, W, stream)) return 1;
-    if (st_stem_weight_s2d(reinterpret_cast<const char*>(weights) + r->convs[0].woff * es, s2dw, dt, r->cpad0, stream)) return 1;
   } else if (st_nchw_to_nhwc(images_nchw, in8, dt, B, 3, H, W, r->cpad0, stream)) return 1;
 
   BnTable tab; tab.n = (int)r->convs.size();
@@ -374,9 +376,9 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         tab.rep[ci] = rep; stats_used += rep * 2 * c.cout;
         g.stats = stats + tab.soff[ci]; g.stats_replicas = rep;
       }
-      if (fz && fz->b2b && r->convs[fz->ci].cout == 1024) {
-        // 14 x 14 blocks: conv3 of the previous block (statistics-only pass already run in train mode), its block end and this conv1 in
-        // ONE kernel (conv_c3c1.hip) -- conv3's output chunks are this conv1's K-slabs
+      if (fz && fz->b2b && st_conv_c3c1_supported(r->convs[fz->ci].cin, r->convs[fz->ci].cout, c.cout)) {
+        // 14 x 14 and 28 x 28 blocks: conv3 of the previous block (statistics-only pass already run in train mode), its block end and
+        // this conv1 in ONE kernel (conv_c3c1.hip) -- conv3's output chunks are this conv1's K-slabs
         const ConvL& pc = r->convs[fz->ci];
         const ConvL& c2 = r->convs[fz->c2ci];
         st_conv_c3c1_desc k;
@@ -534,7 +536,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
   if (stem_fused) {
     const ConvL& c0 = r->convs[0];
     char* wfrag = stem;                                 // the 205-MB raw-output buffer is free in this form: 32 KB of it hold the filters
-    if (st_stem_weight_frag(s2dw, wfrag, stream)) return 1;
+    if (st_stem_weight_frag_packed(reinterpret_cast<const char*>(weights) + r->convs[0].woff * es, r->cpad0, wfrag, stream)) return 1;
     st_stem_conv_pool_desc sd;
     memset(&sd, 0, sizeof(sd));
     sd.x_s2d = in8; sd.w_frag = wfrag; sd.y = wide[0]; sd.B = B; sd.H = H; sd.W = W;
@@ -550,6 +552,7 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
     log_launch("stem_pool", "7x7/2 conv + statistics + 3x3/2 pool", 3, 64, 7, 2, H, W, 2.0 * B * h * w * 147.0 * 64,
                (double)B * (H / 2 + 3) * (W / 2 + 3) * 16 * es + (double)B * conv_out(h, 3, 2, 1) * conv_out(w, 3, 2, 1) * 64 * es);
   } else {
+    if (s2d && st_stem_weight_s2d(reinterpret_cast<const char*>(weights) + r->convs[0].woff * es, s2dw, dt, r->cpad0, stream)) return 1;
     if (conv(0, in8, H, W, stem, nullptr, 1, &h, &w, -1, false)) return 1;
     if (train) {   // bn1 + relu folded into the pool: the 64-channel 112x112 map is read once instead of three times
       const ConvL& c0 = r->convs[0];
@@ -619,16 +622,18 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
         res = wide[dsb];
       }
       bool defer = false, b2b = false;
-      // 14 x 14 blocks (256 -> 1024 -> next conv1 1024 -> 256), train AND eval: conv3 + block end + next conv1 as one kernel
-      // (st_conv_c3c1).  Train: conv3 runs here as a statistics-only pass (y == NULL); an identity that still needs its own BatchNorm
-      // (the block after a downsample conv) keeps the separate path.  Eval: conv3 is not launched at all.
-      static const bool c3c1_env = [] { const char* e = getenv("ST_C3C1"); return !e || atoi(e) != 0; }();
+      // 14 x 14 blocks (256 -> 1024 -> next conv1 1024 -> 256) and 28 x 28 blocks (128 -> 512 -> 128), train AND eval: conv3 + block
+      // end + next conv1 as one kernel (st_conv_c3c1).  Train: conv3 runs here as a statistics-only pass (y == NULL); an identity that
+      // still needs its own BatchNorm (the block after a downsample conv) keeps the separate path.  Eval: conv3 is not launched at all.
+      // ST_C3C1: bit 0 = the 14 x 14 blocks, bit 1 = the 28 x 28 blocks (A/B switch; default both)
+      static const int c3c1_env = [] { const char* e = getenv("ST_C3C1"); return e ? atoi(e) : 3; }();
       bool c3c1 = false;
-      if (use_img && c3c1_env && bi + 1 < r->blocks.size()) {
+      if (use_img && (c3c1_env & (c3.cout == 1024 ? 1 : 2)) && bi + 1 < r->blocks.size()) {
         const BlockL& nb = r->blocks[bi + 1];
         const ConvL& n1 = r->convs[nb.c1];
+        // the kernel indexes both fragment-major filter copies with fixed tile permutations: conv3 packed with ntw = 2, conv1 with N / 64
         c3c1 = n1.k == 1 && n1.stride == 1 && c3.k == 1 && c3.stride == 1 && c3.cout == n1.cin && st_conv_c3c1_supported(c3.cin, c3.cout, n1.cout) &&
-               c3.ntw == 2 && use_astat(c3) && n1.ntw == 4 && (!train || b.ds < 0) && (long)B * h2 * w2 * c3.cout * 2 < (1L << 31);
+               c3.ntw == 2 && n1.ntw == n1.cout / 64 && (!train || (fuse2_ && b.ds < 0)) && (long)B * h2 * w2 * c3.cout * 2 < (1L << 31);
       }
       if (c3c1) { defer = true; b2b = true; }
       else if (train && use_img && kfuse_env && bi + 1 < r->blocks.size()) {

@@ -95,6 +95,10 @@ def stem_conv_pool(images, w_packed, cpad, stats=None, stats_replicas=0, gamma=N
     check(lib().st_stem_weight_s2d(_p(w_packed), _p(ws), _DT[dt], cpad, _stream()), "st_stem_weight_s2d")
     wf = torch.empty(64 * 256, device=images.device, dtype=dt)
     check(lib().st_stem_weight_frag(_p(ws), _p(wf), _stream()), "st_stem_weight_frag")
+    wf1 = torch.empty_like(wf)                     # the one-launch form st_resnet_forward uses: must be the same operands
+    check(lib().st_stem_weight_frag_packed(_p(w_packed), int(cpad), _p(wf1), _stream()), "st_stem_weight_frag_packed")
+    if not torch.equal(wf, wf1):
+        raise _lib.ShowTellHipError("st_stem_weight_frag_packed differs from st_stem_weight_frag(st_stem_weight_s2d(.))")
     PH, PW = (H // 2 - 1) // 2 + 1, (W // 2 - 1) // 2 + 1
     out = torch.empty(B, PH, PW, 64, device=images.device, dtype=dt)
     d = StemConvPoolDesc(_p(xs), _p(wf), _p(out), _p(stats), int(stats_replicas), _p(gamma), _p(scale), _p(shift), B, H, W)
@@ -359,7 +363,8 @@ def conv_b2b(raw2, w3_frag, identity, w1_frag, N, bn2, bn3, count, id_bn=None, e
 
 def conv_c3c1(x2, w3_frag, identity, w1_frag, bn2=None, bn3=None, count=None, eps=1e-5, stats=None, stats_replicas=0,
               scale3=None, shift3=None, scale1=None, shift1=None, relu1=True, x_out=None, out=None):
-    """st_conv_c3c1: x = relu(bn3(conv3(a2)) + identity) (-> x_out), y = conv1_next(x) for the 14 x 14 Bottlenecks (256 -> 1024 -> 256).
+    """st_conv_c3c1: x = relu(bn3(conv3(a2)) + identity) (-> x_out), y = conv1_next(x) for the 14 x 14 Bottlenecks (256 -> 1024 -> 256)
+    and the 28 x 28 ones (128 -> 512 -> 128).
     train: bn3 = dict(stats, gamma, beta[, replicas]) (+ bn2 for a raw x2), count; eval: scale3 / shift3 / scale1 / shift1.  Returns (x_out, y)."""
     from ._lib import ConvC3c1Desc
     _dev(x2, w3_frag, identity, w1_frag, stats, x_out, out, scale3, shift3, scale1, shift1)
@@ -367,7 +372,7 @@ def conv_c3c1(x2, w3_frag, identity, w1_frag, bn2=None, bn3=None, count=None, ep
     if x_out is None:
         x_out = torch.empty_like(identity)
     if out is None:
-        out = torch.empty(*x2.shape[:-1], 256, device=x2.device, dtype=torch.bfloat16)
+        out = torch.empty(*x2.shape[:-1], x2.shape[-1], device=x2.device, dtype=torch.bfloat16)
     d = ConvC3c1Desc()
     d.x2, d.w3_frag, d.identity, d.x_out, d.w1_frag, d.y = x2.data_ptr(), w3_frag.data_ptr(), identity.data_ptr(), x_out.data_ptr(), w1_frag.data_ptr(), out.data_ptr()
     d.stats, d.stats_replicas = (stats.data_ptr() if stats is not None else None), int(stats_replicas)
@@ -381,7 +386,7 @@ def conv_c3c1(x2, w3_frag, identity, w1_frag, bn2=None, bn3=None, count=None, ep
         if t is not None:
             setattr(d, nm, t.data_ptr())
     d.relu1 = int(relu1)
-    d.rows, d.C1, d.C2, d.N = rows, x2.shape[-1], identity.shape[-1], 256
+    d.rows, d.C1, d.C2, d.N = rows, x2.shape[-1], identity.shape[-1], out.shape[-1]
     check(lib().st_conv_c3c1(C.byref(d), _stream()), "st_conv_c3c1")
     return x_out, out
 

@@ -454,51 +454,68 @@ def test_conv_b2b_equals_conv3_bn_act_conv1(case):
         assert y is None
 
 
-# ---- st_conv_c3c1: conv3 (256 -> 1024) + block end + next conv1 (1024 -> 256) of the 14 x 14 Bottlenecks in one kernel ----------------
+# ---- st_conv_c3c1: conv3 + block end + next conv1 of the 14 x 14 (256 -> 1024 -> 256) and 28 x 28 (128 -> 512 -> 128) Bottlenecks in one kernel
 C3C1_CASES = [(4, 14, 14), (1, 9, 13), (3, 7, 5), (1, 1, 3), (9, 14, 14)]      # full row blocks, ragged, fewer rows than a tile, many blocks
+C3C1_GEO = [(256, 1024), (128, 512)]                                            # (C1 = N, C2)
 
 
-def _c3c1_data(shape, seed):
+def _c3c1_path(ops, geo):
+    """The separate kernels the engine would otherwise run for this geometry: (conv3, next conv1) and their fragment `ntw`s."""
+    C1, C2 = geo
+    if geo == (256, 1024):
+        return ops.conv1x1_astat, ops.conv1x1_kstream, ops.conv1x1_astat_supported(C1, C2), 4
+    return ops.conv1x1_wreg, ops.conv1x1_wreg, ops.conv1x1_wreg_supported(C1, C2), ops.conv1x1_wreg_supported(C2, C1)
+
+
+def _c3c1_data(shape, seed, geo=(256, 1024)):
     ops = _ops()
     B, H, W = shape
+    C1, C2 = geo
     g = torch.Generator().manual_seed(1000 * seed + B * H + W)
-    x2 = (torch.randn(B, H, W, 256, generator=g) * 1.2 + 0.2).bfloat16().cuda()
-    ident = torch.relu(torch.randn(B, H, W, 1024, generator=g)).bfloat16().cuda()
-    w3 = (torch.randn(1024, 256, 1, 1, generator=g) / 16).bfloat16().float()
-    w1 = (torch.randn(256, 1024, 1, 1, generator=g) / 32).bfloat16().float()
-    w3a = ops.pack_conv_weight_frag(w3.cuda(), ops.conv1x1_astat_supported(256, 1024))
-    w1k = ops.pack_conv_weight_frag(w1.cuda(), 4)
+    x2 = (torch.randn(B, H, W, C1, generator=g) * 1.2 + 0.2).bfloat16().cuda()
+    ident = torch.relu(torch.randn(B, H, W, C2, generator=g)).bfloat16().cuda()
+    w3 = (torch.randn(C2, C1, 1, 1, generator=g) / C1 ** 0.5).bfloat16().float()
+    w1 = (torch.randn(C1, C2, 1, 1, generator=g) / C2 ** 0.5).bfloat16().float()
+    _, _, ntw3, ntw1 = _c3c1_path(ops, geo)
+    assert ntw3 == 2 and ntw1 == C1 // 64                     # the fixed tile permutations conv_c3c1_kernel indexes
+    w3a = ops.pack_conv_weight_frag(w3.cuda(), ntw3)
+    w1k = ops.pack_conv_weight_frag(w1.cuda(), ntw1)
     return g, x2, ident, w3, w1, w3a, w1k
 
 
+@pytest.mark.parametrize("geo", C3C1_GEO)
 @pytest.mark.parametrize("shape", C3C1_CASES)
-def test_conv_c3c1_train_equals_astat_bn_act_kstream_bit_for_bit(shape):
-    """Train mode: x_out == st_bn_act(st_conv1x1_astat(x2; bn2), bn3, res = identity) and y == st_conv1x1_kstream(x_out), bit for bit
-    (same MFMA order, raw conv3 rounded to bf16 at the same point, same coefficients); bn3's statistics from the statistics-only
-    pass (st_conv1x1_astat with y == NULL) equal the writing pass's; y's statistics equal the K-streaming kernel's."""
+def test_conv_c3c1_train_equals_astat_bn_act_kstream_bit_for_bit(shape, geo):
+    """Train mode: x_out == st_bn_act(conv3(x2; bn2), bn3, res = identity) and y == conv1(x_out), bit for bit, where conv3 / conv1 are
+    the kernels the engine otherwise runs (st_conv1x1_astat / st_conv1x1_kstream at 14 x 14, st_conv1x1_wreg for both at 28 x 28): same
+    MFMA order, raw conv3 rounded to bf16 at the same point, same coefficients; bn3's statistics from the statistics-only pass (y == NULL)
+    equal the writing pass's; y's statistics equal the separate conv1's."""
     ops = _ops()
     B, H, W = shape
-    g, x2, ident, w3, w1, w3a, w1k = _c3c1_data(shape, 1)
+    C1, C2 = geo
+    conv3, conv1, _, _ = _c3c1_path(ops, geo)
+    g, x2, ident, w3, w1, w3a, w1k = _c3c1_data(shape, 1, geo)
     n = float(B * H * W)
-    gam2, bet2 = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.5).cuda()
-    gam3, bet3 = (torch.rand(1024, generator=g) + 0.5).cuda(), (torch.randn(1024, generator=g) * 0.5).cuda()
-    x2f = x2.float().reshape(-1, 256)
-    st2 = torch.zeros(3, 512, device="cuda"); st2[1] = torch.cat([x2f.sum(0), (x2f * x2f).sum(0)])
+    gam2, bet2 = (torch.rand(C1, generator=g) + 0.5).cuda(), (torch.randn(C1, generator=g) * 0.5).cuda()
+    gam3, bet3 = (torch.rand(C2, generator=g) + 0.5).cuda(), (torch.randn(C2, generator=g) * 0.5).cuda()
+    x2f = x2.float().reshape(-1, C1)
+    st2 = torch.zeros(3, 2 * C1, device="cuda"); st2[1] = torch.cat([x2f.sum(0), (x2f * x2f).sum(0)])
     bn2 = dict(stats=st2, gamma=gam2, beta=bet2, count=n, replicas=3)
     # the three-kernel path
-    s3 = torch.zeros(4, 2048, device="cuda")
-    raw3 = ops.conv1x1_astat(x2, w3a, 1024, stats=s3, stats_replicas=4, in_bn=bn2)
+    s3 = torch.zeros(4, 2 * C2, device="cuda")
+    raw3 = conv3(x2, w3a, C2, stats=s3, stats_replicas=4, in_bn=bn2)
     x_ref = ops.bn_act(raw3, gam3, bet3, stats=s3, stats_replicas=4, count=n, relu=True, res=ident)
-    s1_ref = torch.zeros(2, 512, device="cuda")
-    y_ref = ops.conv1x1_kstream(x_ref, w1k, 256, stats=s1_ref, stats_replicas=2)
+    s1_ref = torch.zeros(2, 2 * C1, device="cuda")
+    y_ref = conv1(x_ref, w1k, C1, stats=s1_ref, stats_replicas=2)
     # statistics-only pass + the fused kernel
-    s3b = torch.zeros(4, 2048, device="cuda")
-    assert ops.conv1x1_astat(x2, w3a, 1024, stats=s3b, stats_replicas=4, in_bn=bn2, stats_only=True) is None
+    s3b = torch.zeros(4, 2 * C2, device="cuda")
+    assert conv3(x2, w3a, C2, stats=s3b, stats_replicas=4, in_bn=bn2, stats_only=True) is None
     torch.cuda.synchronize()
     np.testing.assert_allclose(s3b.sum(0).cpu().numpy(), s3.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3 * np.sqrt(n))
-    s1 = torch.zeros(2, 512, device="cuda")
+    s1 = torch.zeros(2, 2 * C1, device="cuda")
     x, y = ops.conv_c3c1(x2, w3a, ident, w1k, bn2=bn2, bn3=dict(stats=s3, gamma=gam3, beta=bet3, replicas=4), count=n, stats=s1, stats_replicas=2)
     torch.cuda.synchronize()
+    assert y.shape[-1] == C1
     assert torch.equal(x, x_ref)
     assert torch.equal(y, y_ref)
     np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s1_ref.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
@@ -512,22 +529,25 @@ def test_conv_c3c1_train_equals_astat_bn_act_kstream_bit_for_bit(shape):
     assert (y.float().cpu().permute(0, 3, 1, 2) - yf).abs().max().item() <= 1.5e-2 * yf.abs().max().item()
     # x2 already normalised (bn2 = None): the loader copies it
     a2d = ops.bn_act(x2, gam2, bet2, stats=st2, stats_replicas=3, count=n, relu=True)
-    x_b, y_b = ops.conv_c3c1(a2d, w3a, ident, w1k, bn3=dict(stats=s3, gamma=gam3, beta=bet3, replicas=4), count=n, stats=torch.zeros(1, 512, device="cuda"), stats_replicas=1)
+    x_b, y_b = ops.conv_c3c1(a2d, w3a, ident, w1k, bn3=dict(stats=s3, gamma=gam3, beta=bet3, replicas=4), count=n, stats=torch.zeros(1, 2 * C1, device="cuda"), stats_replicas=1)
     assert torch.equal(x_b, x_ref) and torch.equal(y_b, y_ref)
 
 
+@pytest.mark.parametrize("geo", C3C1_GEO)
 @pytest.mark.parametrize("shape", C3C1_CASES[:3])
-def test_conv_c3c1_eval_equals_astat_residual_then_kstream(shape):
-    """Eval mode (folded BatchNorms): x_out == st_conv1x1_astat(.., scale3, shift3, relu, residual = identity), y == st_conv1x1_kstream(x_out,
-    scale1, shift1, relu), bit for bit; and both against fp32."""
+def test_conv_c3c1_eval_equals_astat_residual_then_kstream(shape, geo):
+    """Eval mode (folded BatchNorms): x_out == conv3(.., scale3, shift3, relu, residual = identity), y == conv1(x_out, scale1, shift1,
+    relu) of the separate kernels, bit for bit; and both against fp32."""
     ops = _ops()
-    g, x2, ident, w3, w1, w3a, w1k = _c3c1_data(shape, 2)
+    C1, C2 = geo
+    conv3, conv1, _, _ = _c3c1_path(ops, geo)
+    g, x2, ident, w3, w1, w3a, w1k = _c3c1_data(shape, 2, geo)
     x2 = torch.relu(x2)
-    sc3, sh3 = (torch.rand(1024, generator=g) + 0.5).cuda(), (torch.randn(1024, generator=g) * 0.3).cuda()
-    sc1, sh1 = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.3).cuda()
-    x_ref = ops.conv1x1_astat(x2, w3a, 1024, scale=sc3, shift=sh3, relu=True, residual=ident)
+    sc3, sh3 = (torch.rand(C2, generator=g) + 0.5).cuda(), (torch.randn(C2, generator=g) * 0.3).cuda()
+    sc1, sh1 = (torch.rand(C1, generator=g) + 0.5).cuda(), (torch.randn(C1, generator=g) * 0.3).cuda()
+    x_ref = conv3(x2, w3a, C2, scale=sc3, shift=sh3, relu=True, residual=ident)
     for relu1 in (True, False):
-        y_ref = ops.conv1x1_kstream(x_ref, w1k, 256, scale=sc1, shift=sh1, relu=relu1)
+        y_ref = conv1(x_ref, w1k, C1, scale=sc1, shift=sh1, relu=relu1)
         x, y = ops.conv_c3c1(x2, w3a, ident, w1k, scale3=sc3, shift3=sh3, scale1=sc1, shift1=sh1, relu1=relu1)
         torch.cuda.synchronize()
         assert torch.equal(x, x_ref)
