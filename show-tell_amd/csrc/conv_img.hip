@@ -838,14 +838,17 @@ struct AsArgs {
 // piece of tile i of chunk c is REQUESTED in K-step i of chunk c and consumed in K-step i of chunk c + 1 (where chunk c's epilogue
 // runs), i.e. a full chunk (KS K-steps, 2 KS filter loads) ahead: unconditional, clamped rows -- the counted waits of the filter ring
 // stay counted.  No statistics in this form.
-template <int K, int NCH, bool AFFINE, bool STRIDED, bool RES = false>
+// NTW = 4 (64 channels per wave and chunk; statistics only): every 16-row operand read from LDS feeds four MFMAs instead of two.  The filters
+// stay in the ntw = 2 packing (what st_conv_c3c1 indexes): only the channel a lane's sums belong to changes (stats_park).
+template <int K, int NCH, bool AFFINE, bool STRIDED, bool RES = false, int NTW = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_astat_kernel(AsArgs a) {
   static_assert(!RES || (AFFINE && !STRIDED), "the residual epilogue is the eval-mode conv3 form");
+  static_assert(NTW == 2 || (NTW == 4 && !AFFINE && !RES), "NTW = 4 is the statistics-only form");
   // NCH chunks of 128 output channels (32 per wave, NTW = 2).  TWO accumulator sets alternate by chunk: the epilogue of chunk c-1
   // (accumulator reads, statistics, bf16 packing, stores: ~600 VALU instructions) is spread over the K-steps of chunk c, one
   // 16-row tile per K-step, so it runs under that chunk's MFMAs instead of between two MFMA blocks (measured before: 3.5 us per
   // 256-channel chunk of which 1.5 us MFMA).
-  constexpr int TM = 7, NTW = 2, BM = 16 * TM, CW = 64 * NTW;       // CW channels per chunk
+  constexpr int TM = 7, BM = 16 * TM, CW = 64 * NTW;                // CW channels per chunk
   constexpr int PIX = 2 * K + 32, KS = K / 32, CH8 = K / 8;
   constexpr int RPP = 256 / CH8, NL = BM / RPP;                      // rows per loader pass, loads per thread
   constexpr int WR = 6;
@@ -996,6 +999,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
         }
       }
+      if constexpr (NTW == 2)
       if (a.y)   // y == NULL: statistics only (st_conv_c3c1 recomputes the output where it is consumed)
         st_out_store16(a.y, ((long)m * a.N + ch0 * CW + cb) * 2,
                        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
@@ -1008,8 +1012,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int c = 0; c < NC; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
       if (r16 == 0) {
+        if constexpr (NTW == 2) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { sstat[cb + c] = es[c]; sstat[CW * NCH + cb + c] = ess[c]; }
+          for (int c = 0; c < NC; ++c) { sstat[cb + c] = es[c]; sstat[CW * NCH + cb + c] = ess[c]; }
+        } else {   // tile 4 G + j of the ntw = 2 packing, row 4 q4 + e: channel 64 G + 32 (j / 2) + 8 q4 + 4 (j % 2) + e
+          const int g64 = (ch * 4 + wid) * 64 + 8 * q4;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int o = g64 + 32 * ((c >> 2) >> 1) + 4 * ((c >> 2) & 1) + (c & 3);
+            sstat[o] = es[c]; sstat[CW * NCH + o] = ess[c];
+          }
+        }
       }
     }
   };
@@ -1474,19 +1487,20 @@ int launch_ks(KsArgs& a, hipStream_t st, double flops) {
 }  // namespace
 
 namespace {
-template <int K, int NCH, bool AFFINE, bool STRIDED, bool RES = false>
+template <int K, int NCH, bool AFFINE, bool STRIDED, bool RES = false, int NTW = 2>
 int launch_as__(AsArgs& a, hipStream_t st, double flops) {
-  constexpr int lds = 112 * (2 * K + 32) + 2 * 128 * NCH * 4 + 2 * K * 4 + (AFFINE ? 2 * 128 * NCH * 4 : 0);
+  constexpr int BM = 112;
+  constexpr int lds = BM * (2 * K + 32) + 2 * 64 * NTW * NCH * 4 + 2 * K * 4 + (AFFINE ? 2 * 64 * NTW * NCH * 4 : 0);
   static_assert(lds <= 160 * 1024, "activation block does not fit");
   static int attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED, RES, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
   StProfScope prof(K == 256 ? 18 : 19, flops, st);
-  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED, RES>), dim3(((a.M + 111) / 112) * a.nq), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_astat_kernel<K, NCH, AFFINE, STRIDED, RES, NTW>), dim3(((a.M + BM - 1) / BM) * a.nq), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
@@ -1528,6 +1542,12 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)M * d->N * d->C;
   a.nq = 1;
+  // 256 -> 1024, statistics only (train-mode conv3 of the 14 x 14 blocks, recomputed by st_conv_c3c1): 224-row workgroups x two channel parts
+  // 256 -> 1024, statistics only (train-mode conv3 of the 14 x 14 blocks, recomputed by st_conv_c3c1): 64 channels per wave and chunk.
+  // Measured (tools/as_stamps.py stats): 21.35 -> 20.2 us per launch.  A (224 rows, two channel parts) form that halves the filter bytes
+  // per workgroup measured no gain: this pass is not bound by the L2 -> CU path.  ST_ASTAT_NTW4=0: A/B switch
+  static const bool ntw4_env = [] { const char* e = getenv("ST_ASTAT_NTW4"); return !e || atoi(e) != 0; }();
+  if (d->C == 256 && !strided && !a.y && ntw4_env) return launch_as__<256, 4, false, false, false, 4>(a, st, flops);
   if (d->C == 256) return strided ? launch_as_<256, 4, true>(a, st, flops) : launch_as_<256, 8, false>(a, st, flops);
   if (strided) return launch_as_<512, 8, true>(a, st, flops);
   // 512 -> 2048: with <= 128 row blocks the channels are cut in four parts (56 row blocks at 7 x 7, B = 128: 224 workgroups)

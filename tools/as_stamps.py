@@ -5,6 +5,7 @@ import numpy as np, torch
 from showtell_amd import ops
 from showtell_amd._lib import lib
 B, h, c, n = 128, 14, 256, 1024
+STATS_ONLY = len(sys.argv) > 1 and sys.argv[1] == "stats"      # the statistics-only pass (y == NULL) of the train-mode 14 x 14 conv3
 xs = [torch.randn(B, h, h, c, device="cuda").bfloat16() for _ in range(3)]
 w = torch.randn(n, c, 1, 1, device="cuda") / c ** 0.5
 wf = ops.pack_conv_weight_frag(w, ops.conv1x1_astat_supported(c, n))
@@ -13,7 +14,8 @@ x2 = xs[0].float().reshape(-1, c)
 ist = torch.cat([x2.sum(0), (x2 * x2).sum(0)]).contiguous()
 g_, b_ = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
 y = torch.empty(B, h, h, n, device="cuda", dtype=torch.bfloat16)
-run = lambda x: ops.conv1x1_astat(x, wf, n, stats=st, stats_replicas=4, out=y, in_bn=dict(stats=ist, gamma=g_, beta=b_, count=float(B * h * h)))
+run = lambda x: ops.conv1x1_astat(x, wf, n, stats=st, stats_replicas=4, out=None if STATS_ONLY else y, stats_only=STATS_ONLY,
+                                  in_bn=dict(stats=ist, gamma=g_, beta=b_, count=float(B * h * h)))
 for x in xs: run(x)
 torch.cuda.synchronize()
 buf = torch.zeros(8 * 4 * 4096, dtype=torch.int64, device="cuda")
@@ -31,7 +33,7 @@ print(f"3 launches: {e0.elapsed_time(e1) * 1e3 / 3:.1f} us each")
 s = buf.cpu().numpy().reshape(-1, 8)
 s = s[s[:, 0] != 0].astype(np.float64)
 d = np.diff(s[:, :6], axis=1) / 2400.0
-for i, nm in enumerate(["filter prefetch + fill", "chunk 0", "chunks 1-3 (+ epilogues 0-2)", "chunks 4-7 + last epilogue", "statistics flush"]):
+for i, nm in enumerate(["filter prefetch + fill", "chunk 0", "first half of the chunks", "second half + last epilogue", "statistics flush"]):
     print(f"  {nm:>40}: mean {d[:, i].mean():6.2f} us  p10 {np.percentile(d[:, i], 10):6.2f}  p90 {np.percentile(d[:, i], 90):6.2f}")
 print(f"  wave total {d.sum(1).mean():.2f} us over {len(s)} waves")
 
