@@ -1546,6 +1546,8 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   // 256 -> 1024, statistics only (train-mode conv3 of the 14 x 14 blocks, recomputed by st_conv_c3c1): 64 channels per wave and chunk.
   // Measured (tools/as_stamps.py stats): 21.35 -> 20.2 us per launch.  A (224 rows, two channel parts) form that halves the filter bytes
   // per workgroup measured no gain: this pass is not bound by the L2 -> CU path.  ST_ASTAT_NTW4=0: A/B switch
+  // (a dedicated kernel with a 224 x 256 tile per workgroup, one accumulator set: inner loop at the MFMA rate (3.4 us per 256-channel chunk),
+  // but the fill (4.4 us) and the now unhidden chunk epilogues (2 x 1.6 us) took back what the walk gained: 14.8 against 14.2 us per wave)
   static const bool ntw4_env = [] { const char* e = getenv("ST_ASTAT_NTW4"); return !e || atoi(e) != 0; }();
   if (d->C == 256 && !strided && !a.y && ntw4_env) return launch_as__<256, 4, false, false, false, 4>(a, st, flops);
   if (d->C == 256) return strided ? launch_as_<256, 4, true>(a, st, flops) : launch_as_<256, 8, false>(a, st, flops);
