@@ -34,6 +34,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
 }
 typedef __attribute__((ext_vector_type(2))) float f32x2_;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+typedef __attribute__((ext_vector_type(2))) short i16x2_;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   // ONE v_cvt_pk_bf16_f32 (RNE, NaN-preserving); two scalar casts + shift + or compiled to four instructions
   const bf16x2_ b = __builtin_convertvector(f32x2_{lo, hi}, bf16x2_);
