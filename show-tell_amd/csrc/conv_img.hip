@@ -124,7 +124,7 @@ __device__ __forceinline__ void conv3x3_img_body(const ImgArgs& a) {
   // ---- fill: padded band [rows + 2][Wp] (+ everything a discarded position may touch, zeroed) ---------------------
   // Every global load of the band is in flight before the first LDS write; the producer's BatchNorm coefficients are
   // derived meanwhile (replicated statistics are summed here: no separate reduction launch).
-  constexpr int CHH = CH8 / 2, U2 = 19;                            // HALVES == 2: chunks per pixel per half; passes of 16 pixels (<= 297 LDS pixels)
+  constexpr int CHH = CH8 / 2, U2 = TM >= 14 ? 19 : TM + 3;        // HALVES == 2: chunks per pixel per half; passes of 16 pixels (<= 297 | 16 TM + 48 LDS pixels)
   u32x4 v1[HALVES == 2 ? U2 : 1]; bool ok1[HALVES == 2 ? U2 : 1];  // second channel half: loaded now, written under the first half's MFMAs
   float sc1[8], sh1[8];
   const int cch2 = tid % CHH, pp2 = tid / CHH;
@@ -1284,13 +1284,14 @@ int launch_img_(const ImgArgs& a, int lds, hipStream_t st, double flops) {
   static int attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
+  constexpr bool OCC2 = C == 64 || (C == 256 && TM == 7);           // two workgroups per CU: the 64-channel form, the half-band 256-channel form
   if (dev >= 0 && dev < 64 && attr_set[dev] < lds) {
-    if constexpr (C == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel_occ2<C, TM, NTW, HALVES, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (OCC2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel_occ2<C, TM, NTW, HALVES, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_img_kernel<C, TM, NTW, HALVES, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 160 * 1024;
   }
   StProfScope prof(C == 64 ? 8 : C == 128 ? 9 : C == 256 ? 10 : 11, flops, st);
-  if constexpr (C == 64) hipLaunchKernelGGL((conv3x3_img_kernel_occ2<C, TM, NTW, HALVES, AFFINE>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
+  if constexpr (OCC2) hipLaunchKernelGGL((conv3x3_img_kernel_occ2<C, TM, NTW, HALVES, AFFINE>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((conv3x3_img_kernel<C, TM, NTW, HALVES, AFFINE>), dim3(a.B * a.bands * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
@@ -1327,6 +1328,13 @@ extern "C" int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream) {
   a.stats = d->stats; a.srep = d->stats_replicas; a.scale = d->scale; a.shift = d->shift; a.relu = d->relu;
   a.in_stats = d->in_stats; a.in_gamma = d->in_gamma; a.in_beta = d->in_beta; a.in_count = d->in_count; a.in_eps = d->in_eps; a.in_srep = d->in_stats_replicas > 1 ? d->in_stats_replicas : 1;
   a.B = d->B; a.H = d->H; a.W = d->W; a.N = d->N; a.Wp = d->W + 2;
+  // C = 256, half-image bands: 7 row tiles per workgroup, 81 KB of LDS and <= 256 registers, TWO workgroups per CU -- one's
+  // fill and epilogue run under the other's K loop; each streams the filter slice for half the rows (twice the L2 -> CU filter bytes per CU).
+  // Measured (B = 128, 14 x 14): 37.0 -> 33.7 us per launch, wave total 25.2 -> 19.0 us (K loop 17.7 -> 12.4 us per half band with two waves per
+  // SIMD filling each other's stalls), train forward 4.19 -> 4.08 ms.  ST_IMG256_HALF=0: the one-workgroup-per-image form (A/B switch)
+  static const bool half_env = [] { const char* e = getenv("ST_IMG256_HALF"); return !e || atoi(e) != 0; }();
+  const bool half256 = half_env && d->C == 256 && d->W + 2 <= 16 && d->H > 7 * 16 / (d->W + 2);
+  if (half256) c.tm = 7;
   a.R = 16 * c.tm / a.Wp; if (a.R > d->H) a.R = d->H;
   a.bands = (d->H + a.R - 1) / a.R;
   a.nbn = d->C == 64 ? d->N / (32 * c.ntw) : d->N / (64 * c.ntw);   // C = 64: two channel waves per workgroup (position split)
@@ -1337,7 +1345,7 @@ extern "C" int st_conv3x3_img(const st_conv3x3_img_desc* d, void* stream) {
   switch (d->C) {
     case 64:  return launch_img<64, 16, 2, 1>(a, lds, st, flops);
     case 128: return launch_img<128, 14, 2, 1>(a, lds, st, flops);
-    case 256: return launch_img<256, 14, 2, 2>(a, lds, st, flops);
+    case 256: return half256 ? launch_img<256, 7, 2, 2>(a, lds, st, flops) : launch_img<256, 14, 2, 2>(a, lds, st, flops);
     case 512: return launch_img<512, 4, 2, 1>(a, lds, st, flops);
   }
   st_set_error("st_conv3x3_img: no kernel for C=%d", d->C);
