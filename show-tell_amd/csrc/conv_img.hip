@@ -1079,6 +1079,138 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef AS_STAMP
 }
 
+// =====================================================================================================================
+// The statistics-only pass of the 14 x 14 conv3 (256 -> 1024, train mode; st_conv_c3c1 recomputes the output where it is consumed) with
+// TWO workgroups per CU: 112 rows x one part of the channels per workgroup, ONE accumulator set (<= 256 registers, 67 KB of LDS).  Two
+// waves per SIMD fill each other's stalls (operand reads, filter waits, the chunk epilogue) -- what the second accumulator set and the
+// interleaved epilogue of conv1x1_astat_kernel buy with registers, a second wave buys with occupancy, and the fill of one workgroup can run
+// under the walk of the other.  The parts of a row block read the same rows (L2 hits).
+// Filters in the ntw = 2 packing st_conv_c3c1 indexes.
+template <int K, int NCH>
+__global__ __launch_bounds__(256, 2) void conv1x1_cstat_kernel(AsArgs a) {
+  constexpr int TM = 7, NTW = 2, BM = 16 * TM, CW = 64 * NTW;
+  constexpr int PIX = 2 * K + 32, KS = K / 32, CH8 = K / 8;
+  constexpr int RPP = 256 / CH8, NL = BM / RPP;                      // rows per loader pass, loads per thread
+  constexpr int WR = 4;
+  constexpr int TOT = NCH * KS;
+  static_assert(K <= 256, "one producer channel per thread in the prologue");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sstat = reinterpret_cast<float*>(smem + BM * PIX);          // [2][CW NCH] statistics of this part
+  float* coef = sstat + 2 * CW * NCH;                                // [2][K] producer's scale / shift
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bm, bq;
+  {   // the parts of a row block are neighbours on one XCD (its rows: L2 hits)
+    const int nblk = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    bm = lid / a.nq; bq = lid - bm * a.nq;
+  }
+  const int ch0 = bq * NCH;                                          // first 128-channel chunk of this workgroup
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const u32x4* wl = reinterpret_cast<const u32x4*>(a.w) + lane;
+  auto wfrag = [&](int g, int j) { return wl[((size_t)(((ch0 + g / KS) * 4 + wid) * NTW + j) * KS + g % KS) * 64]; };
+#define CS_STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  CS_STAMP(0);
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  StatHead shd;
+  if (a.in_stats) stat_head_issue(shd, a.in_stats, a.in_srep, K, tid % K, a.in_gamma, a.in_beta);
+  u32x4 wq[WR][NTW];
+#pragma unroll
+  for (int g = 0; g < WR; ++g)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wq[g][j] = wfrag(g, j);
+
+  // ---- fill: 112 rows x K, every load in flight before the first LDS write (rows past M re-read row M - 1; never counted) ----
+  {
+    const int cch = tid % CH8, lrow = tid / CH8;
+    u32x4 v[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int m = bm * BM + lrow + i * RPP;
+      m = m < a.M ? m : a.M - 1;
+      v[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)m * K + cch * 8);
+    }
+    if (a.in_stats) {
+      if (tid < K) stat_head_finish(shd, a.in_stats, a.in_srep, K, tid, 1.0f / a.in_count, a.in_eps, coef[tid], coef[K + tid]);
+      __syncthreads();
+      float sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = coef[cch * 8 + e]; sh[e] = coef[K + cch * 8 + e]; }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) bn_relu_chunk(v[i], sc, sh);
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<u32x4*>(smem + (lrow + i * RPP) * PIX + cch * 16) = v[i];
+  }
+  __syncthreads();
+  CS_STAMP(1);
+
+  // ---- channel walk: no barrier until the flush ----------------------------------------------------------------------------
+  constexpr int NC = 4 * NTW;
+  const char* abase = smem + r16 * PIX + q4 * 16;
+  auto read_a = [&](u32x4 (&f)[TM], int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f[i] = *reinterpret_cast<const u32x4*>(abase + i * 16 * PIX + ks * 64);
+  };
+  f32x4 acc[TM][NTW];
+  u32x4 fa0[TM], fa1[TM];
+  read_a(fa0, 0);
+#pragma clang loop unroll(full)
+  for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma clang loop unroll(full)
+    for (int ks = 0; ks < KS; ++ks) {
+      const int g = ch * KS + ks;
+      u32x4 (&fa)[TM] = (g & 1) ? fa1 : fa0;
+      u32x4 (&fn)[TM] = (g & 1) ? fa0 : fa1;
+      if (g + 1 < TOT) read_a(fn, (ks + 1) % KS);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = mfma_bf16(wq[g % WR][j], fa[i], acc[i][j]);
+      if (g + WR < TOT) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) wq[g % WR][j] = wfrag(g + WR, j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch == 0) CS_STAMP(2);
+    // the chunk's sums (rows past M left out), in conv1x1_astat_kernel's order: tiles ascending, then the 16 lanes of a row group
+    float es[NC], ess[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (bm * BM + i * 16 + r16 < a.M) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float v = acc[i][j][e]; es[4 * j + e] += v; ess[4 * j + e] += v * v; }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
+    if (r16 == 0) {
+      const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { sstat[cb + c] = es[c]; sstat[CW * NCH + cb + c] = ess[c]; }
+    }
+    if (ch == NCH / 2 - 1) CS_STAMP(3);
+  }
+  CS_STAMP(4);
+  float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);
+  __syncthreads();
+  for (int t = tid; t < 2 * CW * NCH; t += 256)
+    atomicAdd(sdst + (t < CW * NCH ? ch0 * CW + t : a.N + ch0 * CW + t - CW * NCH), sstat[t]);
+  CS_STAMP(5);
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#undef CS_STAMP
+}
+
 #ifdef ST_EXPERIMENTAL   // measured slower than st_bn_act + st_conv1x1_kstream: kept for A/B runs, not in the product build
 // =====================================================================================================================
 // conv1 of a Bottleneck FUSED WITH THE PREVIOUS BLOCK'S END: x = relu(bn3(raw3) + identity) is what conv1 (1024 -> 256)
@@ -1513,6 +1645,24 @@ int launch_as__(AsArgs& a, hipStream_t st, double flops) {
   ST_LAUNCH_CHECK();
   return 0;
 }
+template <int K, int NCH>
+int launch_cstat(AsArgs& a, hipStream_t st, double flops) {
+  constexpr int lds = 112 * (2 * K + 32) + 2 * 128 * NCH * 4 + 2 * K * 4;
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  static int attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_cstat_kernel<K, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[dev] = 1;
+  }
+  a.nq = a.N / (128 * NCH);
+  StProfScope prof(K == 256 ? 18 : 19, flops, st);
+  hipLaunchKernelGGL((conv1x1_cstat_kernel<K, NCH>), dim3(((a.M + 111) / 112) * a.nq), dim3(256), lds, st, a);
+  prof.end(st);
+  ST_LAUNCH_CHECK();
+  return 0;
+}
 template <int K, int NCH, bool STRIDED>
 int launch_as_(AsArgs& a, hipStream_t st, double flops) {
   if constexpr (!STRIDED) { if (a.res) return launch_as__<K, NCH, true, false, true>(a, st, flops); }
@@ -1556,8 +1706,11 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   // per workgroup measured no gain: this pass is not bound by the L2 -> CU path.  ST_ASTAT_NTW4=0: A/B switch
   // (a dedicated kernel with a 224 x 256 tile per workgroup, one accumulator set: inner loop at the MFMA rate (3.4 us per 256-channel chunk),
   // but the fill (4.4 us) and the now unhidden chunk epilogues (2 x 1.6 us) took back what the walk gained: 14.8 against 14.2 us per wave)
-  static const bool ntw4_env = [] { const char* e = getenv("ST_ASTAT_NTW4"); return !e || atoi(e) != 0; }();
-  if (d->C == 256 && !strided && !a.y && ntw4_env) return launch_as__<256, 4, false, false, false, 4>(a, st, flops);
+  // conv1x1_cstat_kernel: two channel parts per row block, two workgroups per CU (wave total 14.2 -> 11.3 us, train forward 4.16 -> 4.10 ms);
+  // four parts (896 workgroups, 1.75 rounds): no gain.  ST_ASTAT_NTW4 = 1: the one-workgroup-per-CU form above, 0: the 32-channel form (A/B)
+  static const int ntw4_env = [] { const char* e = getenv("ST_ASTAT_NTW4"); return e ? atoi(e) : 2; }();
+  if (d->C == 256 && !strided && !a.y && ntw4_env == 2) return launch_cstat<256, 4>(a, st, flops);
+  if (d->C == 256 && !strided && !a.y && ntw4_env == 1) return launch_as__<256, 4, false, false, false, 4>(a, st, flops);
   if (d->C == 256) return strided ? launch_as_<256, 4, true>(a, st, flops) : launch_as_<256, 8, false>(a, st, flops);
   if (strided) return launch_as_<512, 8, true>(a, st, flops);
   // 512 -> 2048: with <= 128 row blocks the channels are cut in four parts (56 row blocks at 7 x 7, B = 128: 224 workgroups)
