@@ -269,8 +269,8 @@ def main():
             names[16 + i_] = "conv1x1_kstream_kernel<%d,...> (pointwise, long K, csrc/conv_img.hip)" % c_
             prefixes[16 + i_] = ("conv1x1_kstream_kernel<%d," % c_,)
         for i_, c_ in enumerate((256, 512)):
-            names[18 + i_] = "conv1x1_astat_kernel<%d,...> (pointwise, activation-stationary, csrc/conv_img.hip)" % c_
-            prefixes[18 + i_] = ("conv1x1_astat_kernel<%d," % c_,)
+            names[18 + i_] = "conv1x1_astat_kernel<%d,...> + conv1x1_cstat_kernel (pointwise, activation-stationary; statistics-only form, csrc/conv_img.hip)" % c_
+            prefixes[18 + i_] = ("conv1x1_astat_kernel<%d," % c_, "conv1x1_cstat_kernel<%d," % c_)
         names[20] = "stem_pool_kernel (conv 7x7/2 + statistics + 3x3/2 pool in one kernel, csrc/conv_stem.hip)"
         prefixes[20] = ("stem_pool_kernel<",)
         names[21] = "conv_b2b_kernel (conv3 recomputed + bn3 + identity + ReLU (+ next conv1) in one pass, csrc/conv_b2b.hip)"

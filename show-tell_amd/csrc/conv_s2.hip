@@ -37,15 +37,17 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
 }
 
+// C = 128 (56 x 56 -> 28 x 28: 896 workgroups): two workgroups per CU (65 KB of LDS; the register allocation is cut to 256 per wave, ring of
+// 4 K-steps) -- 3.5 rounds of 256 become 1.75 of 512 and two waves per SIMD fill each other's gather and filter waits
 template <int C, int NTW, bool XF, bool AFFINE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3s2_kstream_kernel(S2Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 128 ? 2 : 1, C == 128 ? 2 : 1))) void conv3x3s2_kstream_kernel(S2Args a) {
   constexpr int TM = 7, BM = 16 * TM;
   constexpr int SLAB = 128, PIX = 2 * SLAB + 32, KSS = SLAB / 32;      // 4 K-steps per slab
   constexpr int SPT = C / SLAB;                                        // slabs per tap
   constexpr int NSLAB = 9 * SPT, KS = 9 * C / 32;
   constexpr int SLAB_BYTES = BM * PIX;
   constexpr int NL = BM * (SLAB / 8) / 256;                            // 7 16-byte chunks per thread per slab
-  constexpr int WR = NTW == 4 ? 6 : 8;                                 // filter ring (K-steps in flight)
+  constexpr int WR = NTW == 4 ? 6 : (C == 128 ? 4 : 8);                // filter ring (K-steps in flight)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* coef = reinterpret_cast<float*>(smem + 2 * SLAB_BYTES);       // XF: [scale(C) | shift(C)]
 

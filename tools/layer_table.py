@@ -55,7 +55,7 @@ a, b = all_stems[k_all], (all_stems[k_all + 1] if k_all + 1 < len(all_stems) els
 la, lb = log_starts[k_all], (log_starts[k_all + 1] if k_all + 1 < len(log_starts) else len(log))
 
 FAM = {"igemm": ("igemm_kernel", "igemm_s3b_kernel", "igemm_s3_kernel"), "conv3x3_img": ("conv3x3_img_kernel",), "conv1x1_wreg": ("conv1x1_wreg_kernel",),
-       "conv1x1_astat": ("conv1x1_astat_kernel",), "conv1x1_kstream": ("conv1x1_kstream_kernel",), "conv_b2b": ("conv_b2b_kernel",), "conv_c3c1": ("conv_c3c1_kernel",), "conv3x3_s2": ("conv3x3s2_kstream_kernel",),
+       "conv1x1_astat": ("conv1x1_astat_kernel", "conv1x1_cstat_kernel"), "conv1x1_kstream": ("conv1x1_kstream_kernel",), "conv_b2b": ("conv_b2b_kernel",), "conv_c3c1": ("conv_c3c1_kernel",), "conv3x3_s2": ("conv3x3s2_kstream_kernel",),
        "bn_act": ("bn_act_reg_kernel", "bn_act_kernel"), "stem_pool": ("stem_pool_kernel",), "bn_reduce_replicas": ("bn_reduce_replicas_kernel",)}
 PEAK, HBM = 2.5e15, 6.0e12
 out = []

@@ -13,7 +13,7 @@ def short(name):
     m = re.search(r"igemm_kernelIDF16bLi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         return "igemm_kernel<bf16,%s,%s,%s,%s,%s,mode%s>" % m.groups()
-    m = re.search(r"(conv3x3_img_kernel_occ2|conv3x3_img_kernel|conv1x1_wreg_kernel|conv1x1_kstream_kernel|conv1x1_astat_kernel|conv1x1_kfuse_kernel|conv_b2b_kernel|conv_c3c1_kernel|conv3x3s2_kstream_kernel)<([^>]*)>", name)
+    m = re.search(r"(conv3x3_img_kernel_occ2|conv3x3_img_kernel|conv1x1_wreg_kernel|conv1x1_kstream_kernel|conv1x1_astat_kernel|conv1x1_cstat_kernel|conv1x1_kfuse_kernel|conv_b2b_kernel|conv_c3c1_kernel|conv3x3s2_kstream_kernel)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
     for k in ("igemm_s3b_kernel", "igemm_s3_kernel", "bn_act_reg_kernel", "bn_act_kernel", "vocab_argmax_lds_kernel", "maxpool_kernel",
