@@ -37,17 +37,18 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
 }
 
-// C = 128 (56 x 56 -> 28 x 28: 896 workgroups): two workgroups per CU (65 KB of LDS; the register allocation is cut to 256 per wave, ring of
-// 4 K-steps) -- 3.5 rounds of 256 become 1.75 of 512 and two waves per SIMD fill each other's gather and filter waits
+// C = 128 (56 x 56 -> 28 x 28: 896 workgroups) and C = 256 (28 x 28 -> 14 x 14: 224 row blocks x two 128-channel halves): two workgroups per CU
+// (65 KB of LDS; the register allocation is cut to 256 per wave, ring of 4 K-steps) -- 3.5 rounds of 256 become 1.75 of 512 at C = 128, and two
+// waves per SIMD fill each other's gather and filter waits
 template <int C, int NTW, bool XF, bool AFFINE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 128 ? 2 : 1, C == 128 ? 2 : 1))) void conv3x3s2_kstream_kernel(S2Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 256 ? 2 : 1, C <= 256 ? 2 : 1))) void conv3x3s2_kstream_kernel(S2Args a) {
   constexpr int TM = 7, BM = 16 * TM;
   constexpr int SLAB = 128, PIX = 2 * SLAB + 32, KSS = SLAB / 32;      // 4 K-steps per slab
   constexpr int SPT = C / SLAB;                                        // slabs per tap
   constexpr int NSLAB = 9 * SPT, KS = 9 * C / 32;
   constexpr int SLAB_BYTES = BM * PIX;
   constexpr int NL = BM * (SLAB / 8) / 256;                            // 7 16-byte chunks per thread per slab
-  constexpr int WR = NTW == 4 ? 6 : (C == 128 ? 4 : 8);                // filter ring (K-steps in flight)
+  constexpr int WR = NTW == 4 ? 6 : (C <= 256 ? 4 : 8);                // filter ring (K-steps in flight)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* coef = reinterpret_cast<float*>(smem + 2 * SLAB_BYTES);       // XF: [scale(C) | shift(C)]
 
@@ -278,7 +279,7 @@ int launch_s2(S2Args& a, hipStream_t st, double flops) {
 // > 0: supported, the value is the `ntw` of the fragment-major weights (st_pack_conv_weight_frag with KH = KW = 3); 0: use st_conv
 extern "C" int st_conv3x3_s2_supported(int C, int N) {
   if (C == 128 && N == 128) return 2;
-  if (C == 256 && N == 256) return 4;
+  if (C == 256 && N == 256) return 2;
   if (C == 512 && N == 512) return 2;
   return 0;
 }
@@ -300,6 +301,6 @@ extern "C" int st_conv3x3_s2(const st_conv3x3_img_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)a.M * d->N * 9.0 * d->C;
   if (d->C == 128) return launch_s2<128, 2>(a, st, flops);
-  if (d->C == 256) return launch_s2<256, 4>(a, st, flops);
+  if (d->C == 256) return launch_s2<256, 2>(a, st, flops);
   return launch_s2<512, 2>(a, st, flops);
 }
