@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // interleaved epilogue of conv1x1_astat_kernel buy with registers, a second wave buys with occupancy, and the fill of one workgroup can run
 // under the walk of the other.  The parts of a row block read the same rows (L2 hits).
 // Filters in the ntw = 2 packing st_conv_c3c1 indexes.
-template <int K, int NCH>
+template <int K, int NCH, bool STRIDED, bool AFFINE>
 __global__ __launch_bounds__(256, 2) void conv1x1_cstat_kernel(AsArgs a) {
   constexpr int TM = 7, NTW = 2, BM = 16 * TM, CW = 64 * NTW;
   constexpr int PIX = 2 * K + 32, KS = K / 32, CH8 = K / 8;
@@ -1125,11 +1125,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_cstat_kernel(AsArgs a) {
   {
     const int cch = tid % CH8, lrow = tid / CH8;
     u32x4 v[NL];
+    if constexpr (STRIDED) {   // output row (b, ho, wo) reads input pixel (b, ho * stride, wo * stride): conv1x1_astat_kernel's walk
+      int m0 = bm * BM + lrow;
+      m0 = m0 < a.M ? m0 : a.M - 1;
+      const int hw = a.Ho * a.Wo;
+      int b = m0 / hw, rem = m0 - b * hw, ho = rem / a.Wo, wo = rem - ho * a.Wo, m = m0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      int m = bm * BM + lrow + i * RPP;
-      m = m < a.M ? m : a.M - 1;
-      v[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)m * K + cch * 8);
+      for (int i = 0; i < NL; ++i) {
+        const long src = ((long)b * a.Hin + ho * a.stride) * a.Win + wo * a.stride;
+        v[i] = *reinterpret_cast<const u32x4*>(a.x + src * K + cch * 8);
+        if (m + RPP < a.M) {
+          m += RPP; wo += RPP;
+          while (wo >= a.Wo) { wo -= a.Wo; if (++ho == a.Ho) { ho = 0; ++b; } }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        int m = bm * BM + lrow + i * RPP;
+        m = m < a.M ? m : a.M - 1;
+        v[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)m * K + cch * 8);
+      }
     }
     if (a.in_stats) {
       if (tid < K) stat_head_finish(shd, a.in_stats, a.in_srep, K, tid, 1.0f / a.in_count, a.in_eps, coef[tid], coef[K + tid]);
@@ -1179,33 +1195,57 @@ __global__ __launch_bounds__(256, 2) void conv1x1_cstat_kernel(AsArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (ch == 0) CS_STAMP(2);
-    // the chunk's sums (rows past M left out), in conv1x1_astat_kernel's order: tiles ascending, then the 16 lanes of a row group
-    float es[NC], ess[NC];
+    // the chunk's sums (rows past M left out), in conv1x1_astat_kernel's order: tiles ascending, then the 16 lanes of a row group;
+    // y != NULL: the outputs too (eval: scale / shift / ReLU), straight from the accumulators
+    const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;               // this lane's 8 consecutive channels inside the workgroup's part
+    float es[NC], ess[NC], scv[NC], shv[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; }
+    for (int c = 0; c < NC; ++c) { es[c] = 0.f; ess[c] = 0.f; scv[c] = 1.f; shv[c] = 0.f; }
+    if constexpr (AFFINE) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { scv[c] = a.scale[ch0 * CW + cb + c]; shv[c] = a.shift[ch0 * CW + cb + c]; }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if (bm * BM + i * 16 + r16 < a.M) {
+      const int m = bm * BM + i * 16 + r16;
+      if (m < a.M) {
+        float v[NC];
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float v = acc[i][j][e]; es[4 * j + e] += v; ess[4 * j + e] += v * v; }
+          for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { es[c] += v[c]; ess[c] += v[c] * v[c]; }
+        if constexpr (AFFINE) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) v[c] = v[c] * scv[c] + shv[c];
+          if (a.relu) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = fmaxf(v[c], 0.f);
+          }
+        }
+        if (a.y)
+          st_out_store16(a.y, ((long)m * a.N + ch0 * CW + cb) * 2,
+                         u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
       }
     }
+    if (a.stats) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
-    if (r16 == 0) {
-      const int cb = (ch * 4 + wid) * NTW * 16 + NC * q4;
+      for (int c = 0; c < NC; ++c) { es[c] = row16_sum_(es[c]); ess[c] = row16_sum_(ess[c]); }
+      if (r16 == 0) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) { sstat[cb + c] = es[c]; sstat[CW * NCH + cb + c] = ess[c]; }
+        for (int c = 0; c < NC; ++c) { sstat[cb + c] = es[c]; sstat[CW * NCH + cb + c] = ess[c]; }
+      }
     }
     if (ch == NCH / 2 - 1) CS_STAMP(3);
   }
   CS_STAMP(4);
-  float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);
-  __syncthreads();
-  for (int t = tid; t < 2 * CW * NCH; t += 256)
-    atomicAdd(sdst + (t < CW * NCH ? ch0 * CW + t : a.N + ch0 * CW + t - CW * NCH), sstat[t]);
+  if (a.stats) {
+    float* sdst = a.stats + (a.srep > 1 ? (size_t)(bm % a.srep) * 2 * a.N : 0);
+    __syncthreads();
+    for (int t = tid; t < 2 * CW * NCH; t += 256)
+      atomicAdd(sdst + (t < CW * NCH ? ch0 * CW + t : a.N + ch0 * CW + t - CW * NCH), sstat[t]);
+  }
   CS_STAMP(5);
   if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 #undef CS_STAMP
@@ -1645,23 +1685,28 @@ int launch_as__(AsArgs& a, hipStream_t st, double flops) {
   ST_LAUNCH_CHECK();
   return 0;
 }
-template <int K, int NCH>
-int launch_cstat(AsArgs& a, hipStream_t st, double flops) {
+template <int K, int NCH, bool STRIDED, bool AFFINE>
+int launch_cstat_(AsArgs& a, hipStream_t st, double flops) {
   constexpr int lds = 112 * (2 * K + 32) + 2 * 128 * NCH * 4 + 2 * K * 4;
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
   static int attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_cstat_kernel<K, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_cstat_kernel<K, NCH, STRIDED, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
   a.nq = a.N / (128 * NCH);
   StProfScope prof(K == 256 ? 18 : 19, flops, st);
-  hipLaunchKernelGGL((conv1x1_cstat_kernel<K, NCH>), dim3(((a.M + 111) / 112) * a.nq), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_cstat_kernel<K, NCH, STRIDED, AFFINE>), dim3(((a.M + 111) / 112) * a.nq), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
+}
+template <int K, int NCH>
+int launch_cstat(AsArgs& a, hipStream_t st, double flops) {
+  if (a.stride > 1) return a.scale ? launch_cstat_<K, NCH, true, true>(a, st, flops) : launch_cstat_<K, NCH, true, false>(a, st, flops);
+  return a.scale ? launch_cstat_<K, NCH, false, true>(a, st, flops) : launch_cstat_<K, NCH, false, false>(a, st, flops);
 }
 template <int K, int NCH, bool STRIDED>
 int launch_as_(AsArgs& a, hipStream_t st, double flops) {
@@ -1710,6 +1755,10 @@ extern "C" int st_conv1x1_astat(const st_conv1x1_wreg_desc* d, void* stream) {
   // four parts (896 workgroups, 1.75 rounds): no gain.  ST_ASTAT_NTW4 = 1: the one-workgroup-per-CU form above, 0: the 32-channel form (A/B)
   static const int ntw4_env = [] { const char* e = getenv("ST_ASTAT_NTW4"); return e ? atoi(e) : 2; }();
   if (d->C == 256 && !strided && !a.y && ntw4_env == 2) return launch_cstat<256, 4>(a, st, flops);
+  // the writing forms with 256 input channels and no residual (conv3 of the first 14 x 14 block, the stride-2 downsample conv of layer2): the same
+  // kernel with its stores; N = 512: two parts of two chunks.  ST_ASTAT_OCC2=0: A/B switch
+  static const bool occ2_env = [] { const char* e = getenv("ST_ASTAT_OCC2"); return !e || atoi(e) != 0; }();
+  if (d->C == 256 && a.y && !a.res && occ2_env) return d->N == 1024 ? launch_cstat<256, 4>(a, st, flops) : launch_cstat<256, 2>(a, st, flops);
   if (d->C == 256 && !strided && !a.y && ntw4_env == 1) return launch_as__<256, 4, false, false, false, 4>(a, st, flops);
   if (d->C == 256) return strided ? launch_as_<256, 4, true>(a, st, flops) : launch_as_<256, 8, false>(a, st, flops);
   if (strided) return launch_as_<512, 8, true>(a, st, flops);
