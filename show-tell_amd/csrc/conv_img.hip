@@ -663,9 +663,11 @@ struct KsArgs {
   unsigned long long* stamps;   // debug: per-wave s_memtime at phase boundaries (tools/ks_stamps.py), normally NULL
 };
 
-template <int K, bool STRIDED, bool AFFINE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_kstream_kernel(KsArgs a) {
-  constexpr int TM = 7, NTW = 4, BM = 16 * TM;
+// NTW = 2 (32 channels per wave, 128 per workgroup): <= 256 registers, 65 KB of LDS -- two workgroups per CU (every K = 1024 / 2048 layer except
+// the 1024 -> 256 conv1s, whose ntw = 4 packing st_conv_c3c1 indexes)
+template <int K, bool STRIDED, bool AFFINE, int NTW = 4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTW == 2 ? 2 : 1, NTW == 2 ? 2 : 1))) void conv1x1_kstream_kernel(KsArgs a) {
+  constexpr int TM = 7, BM = 16 * TM;
   constexpr int SLAB = 128, PIX = 2 * SLAB + 32, KSS = SLAB / 32;      // 4 K-steps per slab
   constexpr int NSLAB = K / SLAB, KS = K / 32;
   constexpr int SLAB_BYTES = BM * PIX;
@@ -1643,26 +1645,26 @@ extern "C" int st_conv1x1_wreg(const st_conv1x1_wreg_desc* d, void* stream) {
 }
 
 namespace {
-template <int K, bool STRIDED, bool AFFINE>
+template <int K, bool STRIDED, bool AFFINE, int NTW>
 int launch_ks_(KsArgs& a, hipStream_t st, double flops) {
   constexpr int lds = 2 * 112 * (2 * 128 + 32);
   static int attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_kstream_kernel<K, STRIDED, AFFINE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_kstream_kernel<K, STRIDED, AFFINE, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set[dev] = 1;
   }
   StProfScope prof(K == 1024 ? 16 : 17, flops, st);
-  hipLaunchKernelGGL((conv1x1_kstream_kernel<K, STRIDED, AFFINE>), dim3(((a.M + 111) / 112) * a.nbn), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_kstream_kernel<K, STRIDED, AFFINE, NTW>), dim3(((a.M + 111) / 112) * a.nbn), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
 }
-template <int K>
+template <int K, int NTW>
 int launch_ks(KsArgs& a, hipStream_t st, double flops) {
-  if (a.stride > 1) return a.scale ? launch_ks_<K, true, true>(a, st, flops) : launch_ks_<K, true, false>(a, st, flops);
-  return a.scale ? launch_ks_<K, false, true>(a, st, flops) : launch_ks_<K, false, false>(a, st, flops);
+  if (a.stride > 1) return a.scale ? launch_ks_<K, true, true, NTW>(a, st, flops) : launch_ks_<K, true, false, NTW>(a, st, flops);
+  return a.scale ? launch_ks_<K, false, true, NTW>(a, st, flops) : launch_ks_<K, false, false, NTW>(a, st, flops);
 }
 }  // namespace
 
@@ -1837,7 +1839,13 @@ extern "C" int st_conv1x1_kfuse(const st_conv1x1_kfuse_desc* d, void* stream) {
 }
 
 // 4: supported (the `ntw` of the fragment-major weights); 0: use st_conv
-extern "C" int st_conv1x1_kstream_supported(int K, int N) { return (K == 1024 || K == 2048) && N % 256 == 0 ? 4 : 0; }
+// > 0: supported, the value is the `ntw` of the fragment-major weights.  N = 256 (the 14 x 14 conv1s): 4, the packing st_conv_c3c1 indexes; the
+// other layers (1024 -> 512 / 2048, 2048 -> 512): 2 -- 128 channels per workgroup, two workgroups per CU.  ST_KSTREAM_NTW2=0: 4 everywhere (A/B)
+extern "C" int st_conv1x1_kstream_supported(int K, int N) {
+  static const bool ntw2 = [] { const char* e = getenv("ST_KSTREAM_NTW2"); return !e || atoi(e) != 0; }();
+  if (!((K == 1024 || K == 2048) && N % 256 == 0)) return 0;
+  return (ntw2 && N != 256) ? 2 : 4;
+}
 
 extern "C" int st_conv1x1_kstream(const st_conv1x1_wreg_desc* d, void* stream) {
   ST_CHECK(d && d->x && d->w_frag && d->y, "st_conv1x1_kstream: null pointer");
@@ -1853,10 +1861,12 @@ extern "C" int st_conv1x1_kstream(const st_conv1x1_wreg_desc* d, void* stream) {
   a.Ho = (d->Hin - 1) / d->stride + 1; a.Wo = (d->Win - 1) / d->stride + 1;
   const long M = (long)d->B * a.Ho * a.Wo;
   ST_CHECK(M < (1L << 31) - 4096, "st_conv1x1_kstream: too many rows");
-  a.M = (int)M; a.N = d->N; a.nbn = d->N / 256; a.stamps = st_debug_stamps_ptr();
+  const int ntw = st_conv1x1_kstream_supported(d->C, d->N);
+  a.M = (int)M; a.N = d->N; a.nbn = d->N / (64 * ntw); a.stamps = st_debug_stamps_ptr();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)M * d->N * d->C;
-  return d->C == 1024 ? launch_ks<1024>(a, st, flops) : launch_ks<2048>(a, st, flops);
+  if (ntw == 2) return d->C == 1024 ? launch_ks<1024, 2>(a, st, flops) : launch_ks<2048, 2>(a, st, flops);
+  return d->C == 1024 ? launch_ks<1024, 4>(a, st, flops) : launch_ks<2048, 4>(a, st, flops);
 }
 
 extern "C" int st_pack_conv_weight_frag(const float* w, void* out, int Cout, int Cin, int KH, int KW, int ntw, void* stream) {
