@@ -206,6 +206,132 @@ __global__ __launch_bounds__(256) void softmax_topk_fast_kernel(const float* __r
 }
 
 
+// The same result again, without the per-thread sorted lists (their insertion code ran for nearly every element: with 64 lanes some
+// lane always had a new list entry, 47 us for 1280 x 10000 logits against 8.5 us of HBM time):
+//   pass 1: every thread keeps only its MAXIMUM; the block's k-th largest thread maximum T is a lower bound of the row's k-th largest
+//           element (k threads hold an element >= T), so the row's top k are among the elements >= T;
+//   pass 2: the sum of exponentials in the order of softmax_topk_kernel (probabilities bit-identical) -- and the elements >= T are
+//           appended to a candidate list in LDS (typically k .. 2k entries);
+//   then k rounds of a block-wide arg-max over the candidates, value descending, first index wins: the reference's order.
+// More than 256 candidates (rows of equal logits): the block falls back to a serial selection by one wave over the row.
+__global__ __launch_bounds__(256) void softmax_topk_thr_kernel(const float* __restrict__ logits, int ldl, int V, int k,
+                                                               float* __restrict__ top_p, long* __restrict__ top_id, int raw) {
+  constexpr int CAP = 256, UN = 8;
+  __shared__ float sv[4]; __shared__ int si[4]; __shared__ float ssum[4];
+  __shared__ float cv[CAP]; __shared__ int ci[CAP]; __shared__ int cnt;
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float* l = logits + (long)row * ldl;
+  if (threadIdx.x == 0) cnt = 0;
+  // rows of up to 256 x 40 entries (V = 10000) stay in registers between the passes: the row is read ONCE
+  constexpr int NK = 40;
+  const bool keep = V <= 256 * NK;
+  float rv[NK];
+  float tm = -INFINITY;
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) { const int i = (int)threadIdx.x + 256 * j; rv[j] = i < V ? l[i] : -INFINITY; }
+#pragma unroll
+    for (int j = 0; j < NK; ++j) tm = fmaxf(tm, rv[j]);
+  } else {
+    for (int i0 = threadIdx.x; i0 < V; i0 += UN * 256) {
+      float vv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) vv[u] = i0 + u * 256 < V ? l[i0 + u * 256] : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < UN; ++u) tm = fmaxf(tm, vv[u]);
+    }
+  }
+  float M = wave_max(tm);
+  if (lane == 0) sv[wid] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+  // T = the k-th largest thread maximum (k rounds of a block arg-max over (tm, thread); the winner retires)
+  float T = -INFINITY, mine = tm;
+  for (int j = 0; j < k; ++j) {
+    float best = mine; int bi = (int)threadIdx.x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    best = sv[0]; bi = si[0];
+    for (int w = 1; w < 4; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    if ((int)threadIdx.x == bi) mine = -INFINITY;
+    T = best;
+  }
+  float S = 0.f;
+  auto visit = [&](float v, int i) {                         // (elements in the order of softmax_topk_kernel: i = thread, thread + 256, ..)
+    if (!raw) S += expf(v - M);
+    if (v >= T) { const int p = atomicAdd(&cnt, 1); if (p < CAP) { cv[p] = v; ci[p] = i; } }
+  };
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) { const int i = (int)threadIdx.x + 256 * j; if (i < V) visit(rv[j], i); }
+  } else {
+    for (int i0 = threadIdx.x; i0 < V; i0 += UN * 256) {
+      float vv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) vv[u] = i0 + u * 256 < V ? l[i0 + u * 256] : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { const int i = i0 + u * 256; if (i < V) visit(vv[u], i); }
+    }
+  }
+  if (!raw) {
+    S = wave_sum(S);
+    if (lane == 0) ssum[wid] = S;
+  }
+  __syncthreads();
+  if (!raw) S = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+  const int n = cnt;
+  if (n > CAP) {                                             // (block-uniform) a row with > 256 elements >= T: serial selection by wave 0
+    if (wid == 0) {
+      int chosen[32];
+      for (int j = 0; j < k; ++j) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int i = lane; i < V; i += 64) {
+          bool used = false;
+          for (int q = 0; q < j; ++q) used |= (chosen[q] == i);
+          const float v = l[i];
+          if (!used && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (bi >= V) bi = 0;
+        chosen[j] = bi;
+        if (lane == 0) { top_id[(long)row * k + j] = bi; top_p[(long)row * k + j] = raw ? best : expf(best - M) / S; }
+      }
+    }
+    return;
+  }
+  float myv = (int)threadIdx.x < n ? cv[threadIdx.x] : -INFINITY;
+  int myi = (int)threadIdx.x < n ? ci[threadIdx.x] : 0x7fffffff;
+  for (int j = 0; j < k; ++j) {
+    float best = myv; int bi = myi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    best = sv[0]; bi = si[0];
+    for (int w = 1; w < 4; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    if (myi == bi && bi != 0x7fffffff) { myv = -INFINITY; myi = 0x7fffffff; }
+    if (bi >= V) bi = 0;
+    if (threadIdx.x == 0) {
+      top_id[(long)row * k + j] = bi;
+      top_p[(long)row * k + j] = raw ? best : expf(best - M) / S;
+    }
+  }
+}
+
 // Vocabulary projection with a fused running arg-max: logits[m][n] = h[m] . W[n] + b[n] are never written; per row the
 // (value, first index) maximum is merged into a packed 64-bit key by atomic max.  One block = 16 rows x 128 vocabulary
 // entries; a wave owns two 16-entry tiles and requests all of a tile's K fragments before its first MFMA.
@@ -648,7 +774,10 @@ extern "C" int st_softmax_topk(const float* logits, int ldl, int n, int V, int k
   // cross-check (ST_TOPK_SLOW=1)
   static int slow = -1;
   if (slow < 0) { const char* e = getenv("ST_TOPK_SLOW"); slow = e ? atoi(e) : 0; }
-  if (k <= 5 && !slow && (long)k * 256 <= V)
+  static const bool thr = [] { const char* e = getenv("ST_TOPK_THR"); return !e || atoi(e) != 0; }();   // A/B switch: 0 = the sorted-list form
+  if (k <= 8 && !slow && thr && (long)k * 256 <= V)
+    hipLaunchKernelGGL(softmax_topk_thr_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
+  else if (k <= 5 && !slow && (long)k * 256 <= V)
     hipLaunchKernelGGL(softmax_topk_fast_kernel<5>, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
   else if (k <= 8 && !slow && (long)k * 256 <= V)
     hipLaunchKernelGGL(softmax_topk_fast_kernel<8>, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl, V, k, top_p, top_id, raw);
