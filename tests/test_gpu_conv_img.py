@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 
 # (B, H, W, C, N)
 CASES = [
-    (3, 14, 14, 256, 256),     # layer3 conv2: one image per workgroup
+    (3, 14, 14, 256, 256),     # layer3 conv2: two 7-row bands per image, two workgroups per CU
+    (2, 13, 11, 256, 256),     # the same form, ragged: bands of 8 + 5 rows at Wp = 13
+    (2, 20, 14, 256, 128),     # ... three bands (7 + 7 + 6 rows), one channel half
     (2, 28, 28, 128, 128),     # layer2 conv2: 4 bands of 7 rows
     (2, 56, 56, 64, 64),       # layer1 conv2: 14 bands of 4 rows, all filters in registers
     (5, 7, 7, 512, 512),       # layer4 conv2
