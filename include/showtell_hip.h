@@ -423,6 +423,20 @@ int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, const st_pack
                     const void* x0_override, const void* dlogits, int ldd, const float* dy_top,
                     void* workspace, size_t workspace_bytes, float* dfeat, float* dx0_out, void* stream);
 
+/* Vocabulary projection (rnn.py:33) + nn.CrossEntropyLoss() (main.py:94,149) WITHOUT a logits tensor (csrc/vocab_ce.hip; bf16, H = 512):
+ * after st_rnn_forward(.., logits = NULL, .., targets, save_for_backward = 1):
+ *   st_rnn_fused_loss:    *loss_accum += mean_r( logsumexp(x_r) - x_r[target_r] ), x = y_top W_lin^T + b_lin computed tile by tile;
+ *                         `scratch` (st_rnn_fused_loss_bytes) keeps the rows' logsumexp for the backward call;
+ *   st_rnn_fused_dlogits: dlogits[ntok][ldd] (bf16) = (softmax - onehot) / ntok * *grad_scale_dev from the same tile products, pad columns
+ *                         [V, ldd) zero: the operand st_rnn_backward takes.
+ * Replaces st_rnn_forward's logits + two st_cross_entropy passes (the logits are never written, dlogits once). */
+int st_rnn_fused_loss_supported(const st_rnn_params* p);
+size_t st_rnn_fused_loss_bytes(const st_rnn_params* p, const st_packed_seq* s);
+int st_rnn_fused_loss(const st_rnn_params* p, const st_packed_seq* s, const void* workspace, size_t workspace_bytes,
+                      const long* targets, float* scratch, size_t scratch_bytes, float* loss_accum, void* stream);
+int st_rnn_fused_dlogits(const st_rnn_params* p, const st_packed_seq* s, const void* workspace, size_t workspace_bytes,
+                         const long* targets, const float* scratch, const float* grad_scale_dev, void* dlogits, int ldd, void* stream);
+
 /* nn.CrossEntropyLoss() (mean) forward + backward (main.py:94,149):
  *   *loss_accum += mean_r( logsumexp(x_r) - x_r[target_r] );  dlogits = (softmax - onehot) * grad_scale / rows
  * dlogits may alias logits when the dtypes match; pad columns [V, ldd) are zero-filled. */

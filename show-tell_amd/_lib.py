@@ -156,6 +156,10 @@ _SIGS = {
     "st_rnn_vocab_ld": ([c_i], c_i),
     "st_rnn_workspace_bytes": ([C.POINTER(RnnParams), C.POINTER(PackedSeq)], C.c_size_t),
     "st_rnn_forward": ([C.POINTER(RnnParams), C.POINTER(PackedSeq), c_p, c_p, c_p, C.c_size_t, c_p, c_i, c_i, c_p, c_i, c_p], c_i),
+    "st_rnn_fused_loss_supported": ([C.POINTER(RnnParams)], c_i),
+    "st_rnn_fused_loss_bytes": ([C.POINTER(RnnParams), C.POINTER(PackedSeq)], C.c_size_t),
+    "st_rnn_fused_loss": ([C.POINTER(RnnParams), C.POINTER(PackedSeq), c_p, C.c_size_t, c_p, c_p, C.c_size_t, c_p, c_p], c_i),
+    "st_rnn_fused_dlogits": ([C.POINTER(RnnParams), C.POINTER(PackedSeq), c_p, C.c_size_t, c_p, c_p, c_p, c_p, c_i, c_p], c_i),
     "st_rnn_backward": ([C.POINTER(RnnParams), C.POINTER(RnnGrads), C.POINTER(PackedSeq), c_p, c_p, c_i, c_p, c_p, C.c_size_t,
                          c_p, c_p, c_p], c_i),
     "st_rnn_greedy_workspace_bytes": ([C.POINTER(RnnParams), c_i], C.c_size_t),

@@ -172,6 +172,40 @@ extern "C" int st_rnn_forward(const st_rnn_params* p, const st_packed_seq* s, co
   return 0;
 }
 
+// ---- vocabulary projection + nn.CrossEntropyLoss() fused (csrc/vocab_ce.hip): the logits are never written ---------------------------------
+// scratch (floats): lse[ntok] | target logit[ntok] | partial[ntok][tiles][2]; lse stays valid for st_rnn_fused_dlogits
+extern "C" int st_rnn_fused_loss_supported(const st_rnn_params* p) {
+  return p && p->w_lin && p->b_lin && vocab_ce_supported(p->dtype, p->H) ? 1 : 0;
+}
+extern "C" size_t st_rnn_fused_loss_bytes(const st_rnn_params* p, const st_packed_seq* s) {
+  if (!p || !s) return 0;
+  return ((size_t)s->ntok * (2 + 2 * (size_t)vocab_ce_tiles(p->V))) * sizeof(float);
+}
+extern "C" int st_rnn_fused_loss(const st_rnn_params* p, const st_packed_seq* s, const void* workspace, size_t workspace_bytes,
+                                 const long* targets, float* scratch, size_t scratch_bytes, float* loss_accum, void* stream) {
+  if (check_common(p, s, "st_rnn_fused_loss")) return 1;
+  ST_CHECK(workspace && targets && scratch && loss_accum, "st_rnn_fused_loss: null pointer");
+  ST_CHECK(st_rnn_fused_loss_supported(p), "st_rnn_fused_loss: needs bf16, H = 512 and the vocabulary projection (use st_rnn_forward's logits + st_cross_entropy)");
+  const Plan q = make_plan(p, s);
+  ST_CHECK(workspace_bytes >= q.total && scratch_bytes >= st_rnn_fused_loss_bytes(p, s), "st_rnn_fused_loss: workspace / scratch too small");
+  const char* ytop = reinterpret_cast<const char*>(workspace) + q.y + (size_t)(p->L - 1) * s->ntok * p->H * q.es;
+  const int n = s->ntok;
+  return vocab_ce_forward(ytop, p->w_lin, p->b_lin, targets, n, p->V, scratch + 2 * (size_t)n, scratch + n, scratch, loss_accum,
+                          reinterpret_cast<hipStream_t>(stream));
+}
+// dlogits[ntok][ldd] (bf16) = (softmax - onehot) / ntok * *grad_scale_dev, from the same tile products; pad columns [V, ldd) zero
+extern "C" int st_rnn_fused_dlogits(const st_rnn_params* p, const st_packed_seq* s, const void* workspace, size_t workspace_bytes,
+                                    const long* targets, const float* scratch, const float* grad_scale_dev, void* dlogits, int ldd, void* stream) {
+  if (check_common(p, s, "st_rnn_fused_dlogits")) return 1;
+  ST_CHECK(workspace && targets && scratch && dlogits, "st_rnn_fused_dlogits: null pointer");
+  ST_CHECK(st_rnn_fused_loss_supported(p), "st_rnn_fused_dlogits: unsupported configuration");
+  const Plan q = make_plan(p, s);
+  ST_CHECK(workspace_bytes >= q.total, "st_rnn_fused_dlogits: workspace too small");
+  const char* ytop = reinterpret_cast<const char*>(workspace) + q.y + (size_t)(p->L - 1) * s->ntok * p->H * q.es;
+  return vocab_ce_dlogits(ytop, p->w_lin, p->b_lin, targets, scratch, s->ntok, p->V, dlogits, ldd, 1.0f, grad_scale_dev,
+                          reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int st_rnn_backward(const st_rnn_params* p, const st_rnn_grads* g, const st_packed_seq* s,
                                const void* x0_override, const void* dlogits, int ldd, const float* dy_top_extra,
                                void* workspace, size_t workspace_bytes, float* dfeat, float* dx0_out, void* stream) {

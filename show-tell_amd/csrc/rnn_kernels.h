@@ -66,6 +66,14 @@ __device__ __forceinline__ float st_lstm_unit(float pi, float pf, float pg, floa
 size_t rnn_greedy_pipe_bytes(const st_rnn_params* p, int B, int steps);
 int rnn_greedy_pipe(const st_rnn_params* p, const void* feat, int B, int steps, void* ws, size_t ws_bytes, long* ids_out, hipStream_t st);
 
+// vocabulary projection + cross entropy without a logits tensor, csrc/vocab_ce.hip
+int vocab_ce_supported(int dtype, int H);
+int vocab_ce_tiles(int V);
+int vocab_ce_forward(const void* y, const void* w, const float* bias, const long* target, int n, int V, float* partial, float* tgt,
+                     float* lse, float* loss, hipStream_t st);
+int vocab_ce_dlogits(const void* y, const void* w, const float* bias, const long* target, const float* lse, int n, int V,
+                     void* dlogits, int ldd, float gscale, const float* gscale_dev, hipStream_t st);
+
 int rnn_gemm_launch(const RnnGemmArgs& a, int dtype, int epi, int has_x, hipStream_t st);
 int rnn_gemm_launch_batch(const RnnGemmArgs* cells, int ncells, int dtype, int epi, int has_x, hipStream_t st);
 int rnn_bwd_gates_launch_batch(const RnnBwdCell* cells, int ncells, int H, int cell_kind, int dtype, hipStream_t st);

@@ -16,6 +16,7 @@ Gradients: the backward kernels accumulate straight into ``param.grad`` (fp32), 
 ``loss.backward()`` the optimizer sees exactly what torch autograd would have produced.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -80,15 +81,26 @@ class _DecoderFn(torch.autograd.Function):
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         V, Vp, n = m.vocab_size, lib().st_rnn_vocab_ld(m.vocab_size), plan.ntok
         targets = torch.empty(n, device=dev, dtype=torch.long)
-        logits = torch.empty(n, Vp, device=dev, dtype=torch.float32 if mode == "logits" else dt)
+        # mode 'loss' in bf16: the vocabulary projection and the cross entropy run tile by tile without a logits tensor (csrc/vocab_ce.hip);
+        # ST_FUSED_CE=0 keeps st_rnn_forward's logits + st_cross_entropy
+        fused = mode == "loss" and os.environ.get("ST_FUSED_CE", "1") != "0" and bool(lib().st_rnn_fused_loss_supported(C.byref(prm)))
+        logits = None if fused else torch.empty(n, Vp, device=dev, dtype=torch.float32 if mode == "logits" else dt)
         check(lib().st_rnn_forward(C.byref(prm), C.byref(seq), None, _cp(featd), _cp(ws), nbytes, _cp(logits),
-                                   ST_F32 if logits.dtype == torch.float32 else ST_BF16, Vp, _cp(targets),
+                                   ST_F32 if (logits is not None and logits.dtype == torch.float32) else ST_BF16, Vp, _cp(targets),
                                    int(need_grad), _stream()), "st_rnn_forward")
         ctx.m, ctx.plan, ctx.caption, ctx.ws, ctx.mode, ctx.keep = m, plan, caption, ws, mode, keep
         ctx.feat_dtype = feat.dtype
+        ctx.fused = fused
         if mode == "logits":
             return logits[:, :V]
         loss = torch.zeros((), device=dev, dtype=torch.float32)
+        if fused:
+            sb = lib().st_rnn_fused_loss_bytes(C.byref(prm), C.byref(seq))
+            scratch = torch.empty(sb // 4, device=dev, dtype=torch.float32)
+            check(lib().st_rnn_fused_loss(C.byref(prm), C.byref(seq), _cp(ws), nbytes, _cp(targets), _cp(scratch), sb, _cp(loss), _stream()),
+                  "st_rnn_fused_loss")
+            ctx.logits, ctx.targets, ctx.scratch = None, targets, scratch
+            return loss
         check(lib().st_cross_entropy(_cp(logits), ST_F32 if dt == torch.float32 else ST_BF16, _cp(targets), n, V, Vp,
                                      _cp(loss), None, 0, Vp, 1.0, None, _stream()), "st_cross_entropy")
         ctx.logits, ctx.targets = logits, targets
@@ -108,6 +120,13 @@ class _DecoderFn(torch.autograd.Function):
             if gs is None:
                 g = g.contiguous(); gs = g.stride(0)
             check(lib().st_cast2d(_cp(g), _cp(dlog), ST_F32, dtc, n, V, gs, Vp, _stream()), "st_cast2d")
+        elif ctx.fused:
+            gsc = gout.detach().float().contiguous()
+            dlog = torch.empty(n, Vp, device=dev, dtype=dt)
+            prm_, keep_ = m._c_params()
+            seq_ = plan.c_struct(ctx.caption)
+            check(lib().st_rnn_fused_dlogits(C.byref(prm_), C.byref(seq_), _cp(ctx.ws), ctx.ws.numel(), _cp(ctx.targets), _cp(ctx.scratch),
+                                             _cp(gsc), _cp(dlog), Vp, _stream()), "st_rnn_fused_dlogits")
         else:
             dlog = ctx.logits   # overwritten in place by (softmax - onehot) * dLoss / N_tok
             gsc = gout.detach().float().contiguous()

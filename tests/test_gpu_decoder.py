@@ -22,6 +22,14 @@ def _rel(got, ref):
     return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
 
 
+def _make_sized(cell, params, dtype, E, H, V, L):
+    from showtell_amd.rnn import RNN
+    from showtell_amd.rnn_lstm import RNN as RNN_LSTM
+    m = (RNN if cell == "gru" else RNN_LSTM)(E, H, V, L, dtype=dtype)
+    m.load_state_dict({k: v.clone() for k, v in params.items()})
+    return m.cuda().train()
+
+
 def _make(cell, params, dtype):
     from showtell_amd.rnn import RNN
     from showtell_amd.rnn_lstm import RNN as RNN_LSTM
@@ -138,6 +146,41 @@ def test_bf16_forward_backward_close_to_oracle(cell):
     loss.backward()
     for k, p in m.named_parameters():
         assert _rel(p.grad, po[k].grad) < 4e-2, k
+
+
+@pytest.mark.parametrize("cell,V,B", [("gru", 777, 9), ("lstm", 1500, 33), ("gru", 256, 4)])
+def test_fused_vocab_cross_entropy_matches_launch_chain_and_oracle(cell, V, B, monkeypatch):
+    """rnn.loss() in bf16 at H = 512 runs the vocabulary projection + cross entropy tile by tile without a logits tensor (csrc/vocab_ce.hip).
+    Ragged sizes (V not a multiple of the 256-entry tile, tokens not a multiple of the 64-token tile, pad columns up to the leading dimension):
+    loss and every gradient against the launch chain (ST_FUSED_CE=0: st_rnn_forward's logits + st_cross_entropy; it rounds the logits to bf16,
+    the fused path keeps the fp32 accumulators) and against the fp32 oracle."""
+    from showtell_amd._lib import lib
+    E, H, L = 512, 512, 2
+    params = R.init_decoder_params(E, H, V, L, cell, seed=5)
+    params = {k: v.bfloat16().float() for k, v in params.items()}
+    cap, lens = R.synthetic_captions(B, V, seed=5, mean=7, std=2, lo=3, hi=11)
+    feat = (torch.randn(B, E, generator=torch.Generator().manual_seed(5))).bfloat16().float()
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ST_FUSED_CE", fused)
+        m = _make_sized(cell, params, torch.bfloat16, E, H, V, L)
+        fd = feat.cuda().requires_grad_(True)
+        loss = m.loss(fd, cap.cuda(), lens)
+        loss.backward()
+        torch.cuda.synchronize()
+        g = {k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}
+        g["feat"] = fd.grad.detach().float().cpu()
+        out[fused] = (loss.item(), g)
+    assert abs(out["1"][0] - out["0"][0]) < 2e-3
+    for k in out["0"][1]:
+        assert _rel(out["1"][1][k], out["0"][1][k]) < 2e-2, k
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    fo = feat.clone().requires_grad_(True)
+    lo, _, _ = R.gru_train_loss(po, fo, cap, lens, cell)
+    lo.backward()
+    assert abs(out["1"][0] - lo.item()) < 2e-2
+    for k, v in po.items():
+        assert _rel(out["1"][1][k], v.grad) < 4e-2, k
 
 
 def test_fp32_full_size_gru_step_matches_oracle():
