@@ -183,6 +183,34 @@ def test_fused_vocab_cross_entropy_matches_launch_chain_and_oracle(cell, V, B, m
         assert _rel(out["1"][1][k], v.grad) < 4e-2, k
 
 
+def test_fused_vocab_cross_entropy_three_sgd_steps_track_the_launch_chain(monkeypatch):
+    """Three SGD steps of the bf16 GRU decoder at H = 512 through rnn.loss() with the fused vocabulary projection + cross entropy against the
+    same three steps on the launch chain: losses and final weights agree to bf16-path tolerance (the fused path keeps fp32 logits)."""
+    from showtell_amd import optim
+    E, H, V, L, B = 512, 512, 1200, 2, 24
+    params = R.init_decoder_params(E, H, V, L, "gru", seed=21)
+    cap, lens = R.synthetic_captions(B, V, seed=21, mean=8, std=2, lo=4, hi=12)
+    feat = torch.randn(B, E, generator=torch.Generator().manual_seed(21)).cuda()
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ST_FUSED_CE", fused)
+        m = _make_sized("gru", params, torch.bfloat16, E, H, V, L)
+        opt = optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = m.loss(feat, cap.cuda(), lens)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        res[fused] = (losses, {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()})
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert abs(a - b) < 5e-3 * max(1.0, abs(b))
+    assert res["1"][0][-1] < res["1"][0][0]                    # the loss goes down
+    for k in res["0"][1]:
+        assert _rel(res["1"][1][k], res["0"][1][k]) < 2e-2, k
+
+
 def test_fp32_full_size_gru_step_matches_oracle():
     """BASELINE config shape: E=H=512, L=5, V=10000, B=128 synthetic captions."""
     E, H, V, L, B = 512, 512, 10000, 5, 128
