@@ -202,6 +202,9 @@ typedef struct {
   float count; float eps;
   const float* scale3; const float* shift3; const float* scale1; const float* shift1; int relu1;
   long rows; int C1, C2, N;
+  /* train, optional: the identity is the RAW output of a downsample conv with these batch statistics (the block behind it):
+   * x_out = relu(bn3(conv3) + batchnorm(identity; id_*)), st_bn_act's res_bn form */
+  const float* id_stats; const float* id_gamma; const float* id_beta; int id_replicas;
 } st_conv_c3c1_desc;
 int st_conv_c3c1_supported(int C1, int C2, int N);
 int st_conv_c3c1(const st_conv_c3c1_desc* d, void* stream);

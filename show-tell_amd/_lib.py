@@ -63,7 +63,8 @@ class ConvC3c1Desc(C.Structure):
                 ("bn3_stats", c_p), ("bn3_gamma", c_p), ("bn3_beta", c_p), ("bn3_replicas", c_i),
                 ("count", c_f), ("eps", c_f),
                 ("scale3", c_p), ("shift3", c_p), ("scale1", c_p), ("shift1", c_p), ("relu1", c_i),
-                ("rows", c_l), ("C1", c_i), ("C2", c_i), ("N", c_i)]
+                ("rows", c_l), ("C1", c_i), ("C2", c_i), ("N", c_i),
+                ("id_stats", c_p), ("id_gamma", c_p), ("id_beta", c_p), ("id_replicas", c_i)]
 
 
 class BnActDesc(C.Structure):

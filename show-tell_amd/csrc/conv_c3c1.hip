@@ -42,6 +42,7 @@ struct C3Args {
   float* stats; int srep;                                            // train: statistics of y [srep][2 x 256]
   const float* s2; const float* g2; const float* b2; int s2rep;      // train: bn2 of x2 (NULL: x2 is already normalised)
   const float* s3; const float* g3; const float* b3; int s3rep;      // train: bn3 from batch statistics
+  const float* sd; const float* gd; const float* bd; int sdrep;      // train, IDBN: the identity is a RAW downsample-conv output; its BatchNorm
   const float* sc3; const float* sh3;                                // eval: folded bn3
   const float* sc1; const float* sh1; int relu1;                     // eval: folded bn1 of the next block (+ ReLU) on y
   float count, eps;
@@ -84,12 +85,17 @@ __device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t rs, int voff, in
 constexpr int CW = 128, PIXS = 2 * CW + 32;                          // chunk width (conv3 output channels = conv1 K-slab), padded slab row
 constexpr int KSB = CW / 32;                                         // conv1 K-steps per slab (4)
 constexpr int NTW3 = 2;                                              // conv3: 16-channel tiles per wave (32 of a chunk's 128)
-template <int K3, int N3, int N1, int TM> constexpr int c3_lds() { return 16 * TM * (2 * K3 + 32) + 2 * 16 * TM * PIXS + 2 * N3 * 4 + 2 * K3 * 4; }
+template <int K3, int N3, int N1, int TM, bool IDBN = false> constexpr int c3_lds() {
+  return 16 * TM * (2 * K3 + 32) + 2 * 16 * TM * PIXS + 2 * N3 * 4 + 2 * K3 * 4 + (IDBN ? 2 * N3 * 4 : 0);
+}
 
 // (K3, N3, N1): conv3 K3 -> N3, next conv1 N3 -> N1.  (256, 1024, 256): the layer3 blocks; (128, 512, 128): the layer2 blocks.
 // TM: 16-row tiles per workgroup; WPE: workgroups per CU the register budget is cut for (waves per SIMD)
-template <int K3, int N3, int N1, int TM, int WPE, bool TRAIN>
+// IDBN (train): the block follows a downsample conv -- the identity arrives RAW with its batch statistics and x = relu(bn3(raw3) + bn_d(identity)),
+// st_bn_act's res_bn form (same arithmetic: bn_d as one FMA, then the add).  Its scale / shift sit in LDS behind bn2's and are read per tile.
+template <int K3, int N3, int N1, int TM, int WPE, bool TRAIN, bool IDBN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_c3c1_kernel(C3Args a) {
+  static_assert(!IDBN || TRAIN, "the identity's BatchNorm is a train-mode form");
   constexpr int BM = 16 * TM, SLAB_BYTES = BM * PIXS;                // rows per workgroup
   constexpr int WR3 = WPE == 1 ? 6 : 4, WR1 = 4;                     // filter rings (K-steps in flight)
   constexpr int PIX3 = 2 * K3 + 32;                                  // padded LDS row of the conv3 input (bytes)
@@ -103,6 +109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   char* slab = smem + A2_BYTES;
   float* coef3 = reinterpret_cast<float*>(smem + A2_BYTES + 2 * SLAB_BYTES);     // [scale(N3) | shift(N3)]
   float* coef2 = coef3 + 2 * N3;                                                // [scale(K3) | shift(K3)] (train)
+  float* coefd = coef2 + 2 * K3;                                                // IDBN: [scale(N3) | shift(N3)] of the identity's BatchNorm
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   // issued) waits for them alone.  Train: the first four replicas of bn3's statistics for this thread's four channels and of bn2's for
   // its one channel (K3 == blockDim), gamma / beta; all unconditional (a NULL bn2 reads bn3's arrays and is ignored).
   float sa[NB3][4], sb[NB3][4], gg[NB3], bb[NB3], s2a[4], s2b[4], g2v = 1.f, b2v = 0.f;
+  float da[IDBN ? NB3 : 1][4], db[IDBN ? NB3 : 1][4], gdv[IDBN ? NB3 : 1], bdv[IDBN ? NB3 : 1];
   const int c2i = tid % K3;                                          // this thread's bn2 channel (K3 <= blockDim)
   if constexpr (TRAIN) {
     const float* s2p = a.s2 ? a.s2 : a.s3;
@@ -143,6 +151,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
     for (int k = 0; k < NB3; ++k) { gg[k] = a.g3[tid + 256 * k]; bb[k] = a.b3[tid + 256 * k]; }
     g2v = g2p[c2i]; b2v = b2p[c2i];
+    if constexpr (IDBN) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rd = q < a.sdrep ? q : a.sdrep - 1;
+#pragma unroll
+        for (int k = 0; k < NB3; ++k) { da[k][q] = a.sd[(size_t)rd * 2 * N3 + tid + 256 * k]; db[k][q] = a.sd[(size_t)rd * 2 * N3 + N3 + tid + 256 * k]; }
+      }
+#pragma unroll
+      for (int k = 0; k < NB3; ++k) { gdv[k] = a.gd[tid + 256 * k]; bdv[k] = a.bd[tid + 256 * k]; }
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < NB3; ++k) { gg[k] = a.sc3[tid + 256 * k]; bb[k] = a.sh3[tid + 256 * k]; }
@@ -194,6 +212,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
           for (int q = 0; q < 4; ++q) { sm += q < a.s3rep ? sa[k][q] : 0.f; sq += q < a.s3rep ? sb[k][q] : 0.f; }
           for (int r = 4; r < a.s3rep; ++r) { sm += a.s3[(size_t)r * 2 * N3 + tid + 256 * k]; sq += a.s3[(size_t)r * 2 * N3 + N3 + tid + 256 * k]; }   // (the engine uses <= 4)
           bn_scale_shift(sm, sq, inv, gg[k], bb[k], a.eps, coef3[tid + 256 * k], coef3[N3 + tid + 256 * k]);
+        }
+      }
+      if constexpr (IDBN) {
+#pragma unroll
+        for (int k = 0; k < NB3; ++k) {
+          float sm = 0.f, sq = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { sm += q < a.sdrep ? da[k][q] : 0.f; sq += q < a.sdrep ? db[k][q] : 0.f; }
+          for (int r = 4; r < a.sdrep; ++r) { sm += a.sd[(size_t)r * 2 * N3 + tid + 256 * k]; sq += a.sd[(size_t)r * 2 * N3 + N3 + tid + 256 * k]; }
+          bn_scale_shift(sm, sq, inv, gdv[k], bdv[k], a.eps, coefd[tid + 256 * k], coefd[N3 + tid + 256 * k]);
         }
       }
       if (a.s2) {
@@ -261,7 +289,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const uint32_t p = pack_bf16x2(r[0], r[1]);
         r = f32x2_{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)};
       }
-      const f32x2_ idv = f32x2_{__uint_as_float(rres[i][d] << 16), __uint_as_float(rres[i][d] & 0xffff0000u)};
+      f32x2_ idv = f32x2_{__uint_as_float(rres[i][d] << 16), __uint_as_float(rres[i][d] & 0xffff0000u)};
+      if constexpr (IDBN) {
+        const float* cd = coefd + ch * CW + wid * 32 + NC3 * q4 + 2 * d;
+        idv = __builtin_elementwise_fma(idv, f32x2_{cd[0], cd[1]}, f32x2_{cd[N3], cd[N3 + 1]});
+      }
       const f32x2_ t = __builtin_elementwise_fma(r, f32x2_{sc[2 * d], sc[2 * d + 1]}, f32x2_{sh[2 * d], sh[2 * d + 1]}) + idv;
       const uint32_t q = pack_bf16x2(t[0], t[1]);
       const i16x2_ m = __builtin_elementwise_max(*reinterpret_cast<const i16x2_*>(&q), i16x2_{0, 0});
@@ -406,19 +438,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #undef C3_STAMP
 }
 
-template <int K3, int N3, int N1, int TM, int WPE, bool TRAIN>
+template <int K3, int N3, int N1, int TM, int WPE, bool TRAIN, bool IDBN = false>
 int launch_c3c1(C3Args& a, hipStream_t st, double flops) {
-  constexpr int lds = c3_lds<K3, N3, N1, TM>(), BM = 16 * TM;
+  constexpr int lds = c3_lds<K3, N3, N1, TM, IDBN>(), BM = 16 * TM;
   static_assert(lds * WPE <= 160 * 1024, "LDS");
   static int attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c3c1_kernel<K3, N3, N1, TM, WPE, TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c3c1_kernel<K3, N3, N1, TM, WPE, TRAIN, IDBN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = 1;
   }
   StProfScope prof(K3 == 256 ? 22 : 24, flops, st);
-  hipLaunchKernelGGL((conv_c3c1_kernel<K3, N3, N1, TM, WPE, TRAIN>), dim3((a.M + BM - 1) / BM), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_c3c1_kernel<K3, N3, N1, TM, WPE, TRAIN, IDBN>), dim3((a.M + BM - 1) / BM), dim3(256), lds, st, a);
   prof.end(st);
   ST_LAUNCH_CHECK();
   return 0;
@@ -439,8 +471,9 @@ extern "C" int st_conv_c3c1(const st_conv_c3c1_desc* d, void* stream) {
   if (train) {
     ST_CHECK(d->bn3_gamma && d->bn3_beta && d->count > 0.f && !d->scale3 && !d->scale1, "st_conv_c3c1: train mode takes bn3 statistics + gamma / beta (and no folded coefficients)");
     ST_CHECK(!d->bn2_stats || (d->bn2_gamma && d->bn2_beta), "st_conv_c3c1: bn2_stats comes with bn2_gamma, bn2_beta");
+    ST_CHECK(!d->id_stats || (d->id_gamma && d->id_beta), "st_conv_c3c1: id_stats comes with id_gamma, id_beta");
   } else {
-    ST_CHECK(d->scale3 && d->shift3 && d->scale1 && d->shift1 && !d->bn2_stats && !d->stats, "st_conv_c3c1: eval mode takes folded scale / shift for bn3 and the next bn1, no statistics");
+    ST_CHECK(d->scale3 && d->shift3 && d->scale1 && d->shift1 && !d->bn2_stats && !d->stats && !d->id_stats, "st_conv_c3c1: eval mode takes folded scale / shift for bn3 and the next bn1, no statistics");
   }
   auto rep = [](int r) { return r > 1 ? r : 1; };
   ST_CHECK(d->stats_replicas >= 0 && d->stats_replicas <= 1024 && d->bn2_replicas >= 0 && d->bn2_replicas <= 1024 && d->bn3_replicas >= 0 && d->bn3_replicas <= 1024, "st_conv_c3c1: bad replicas");
@@ -450,15 +483,18 @@ extern "C" int st_conv_c3c1(const st_conv_c3c1_desc* d, void* stream) {
   a.stats = d->stats; a.srep = d->stats_replicas;
   a.s2 = d->bn2_stats; a.g2 = d->bn2_gamma; a.b2 = d->bn2_beta; a.s2rep = rep(d->bn2_replicas);
   a.s3 = d->bn3_stats; a.g3 = d->bn3_gamma; a.b3 = d->bn3_beta; a.s3rep = rep(d->bn3_replicas);
+  a.sd = d->id_stats; a.gd = d->id_gamma; a.bd = d->id_beta; a.sdrep = rep(d->id_replicas);
   a.sc3 = d->scale3; a.sh3 = d->shift3; a.sc1 = d->scale1; a.sh1 = d->shift1; a.relu1 = d->relu1;
   a.count = d->count; a.eps = d->eps; a.M = (int)d->rows; a.stamps = st_debug_stamps_ptr();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * (double)d->rows * ((double)d->C1 * d->C2 + (double)d->C2 * d->N);
+  if (d->C1 == 256 && a.sd) return launch_c3c1<256, 1024, 256, 7, 1, true, true>(a, st, flops);
   if (d->C1 == 256) return train ? launch_c3c1<256, 1024, 256, 7, 1, true>(a, st, flops) : launch_c3c1<256, 1024, 256, 7, 1, false>(a, st, flops);
   // 28 x 28: 80-row workgroups, two per CU (74 KB of LDS, <= 256 registers): one workgroup's fill / prologue runs under the other's
   // walk, and 100352 rows make 1255 workgroups = 2.45 rounds of 512 slots.  Measured at B = 128 (tools/time_c3c1.py, train | eval):
   // (TM 7, 1 per CU) 80 | 74 us, (4, 2) 80 | 74 (3.06 rounds), (3, 3) 93 | 110 (spills), (5, 2) 67 | 64.  ST_C3C1_L2=7: the (7, 1) form
   static const int l2form = [] { const char* e = getenv("ST_C3C1_L2"); return e ? atoi(e) : 5; }();
+  if (a.sd) return launch_c3c1<128, 512, 128, 5, 2, true, true>(a, st, flops);
   if (l2form == 7) return train ? launch_c3c1<128, 512, 128, 7, 1, true>(a, st, flops) : launch_c3c1<128, 512, 128, 7, 1, false>(a, st, flops);
   return train ? launch_c3c1<128, 512, 128, 5, 2, true>(a, st, flops) : launch_c3c1<128, 512, 128, 5, 2, false>(a, st, flops);
 }

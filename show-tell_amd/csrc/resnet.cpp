@@ -389,6 +389,10 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
           k.stats = g.stats; k.stats_replicas = g.stats_replicas;
           k.bn2_stats = stats + tab.soff[fz->c2ci]; k.bn2_gamma = bn_gamma + c2.bnoff; k.bn2_beta = bn_beta + c2.bnoff; k.bn2_replicas = tab.rep[fz->c2ci];
           k.bn3_stats = stats + tab.soff[fz->ci]; k.bn3_gamma = bn_gamma + pc.bnoff; k.bn3_beta = bn_beta + pc.bnoff; k.bn3_replicas = tab.rep[fz->ci];
+          if (fz->res_ci >= 0) {     // the identity is a raw downsample-conv output: its BatchNorm rides in the kernel's epilogue
+            const ConvL& rc = r->convs[fz->res_ci];
+            k.id_stats = stats + tab.soff[fz->res_ci]; k.id_gamma = bn_gamma + rc.bnoff; k.id_beta = bn_beta + rc.bnoff; k.id_replicas = tab.rep[fz->res_ci];
+          }
           k.count = tab.count[fz->ci]; k.eps = eps;
         } else {
           k.scale3 = fscale + pc.bnoff; k.shift3 = fshift + pc.bnoff; k.scale1 = d.scale; k.shift1 = d.shift; k.relu1 = d.relu;
@@ -627,13 +631,15 @@ extern "C" int st_resnet_forward(const st_resnet* r, const float* images_nchw, i
       // still needs its own BatchNorm (the block after a downsample conv) keeps the separate path.  Eval: conv3 is not launched at all.
       // ST_C3C1: bit 0 = the 14 x 14 blocks, bit 1 = the 28 x 28 blocks (A/B switch; default both)
       static const int c3c1_env = [] { const char* e = getenv("ST_C3C1"); return e ? atoi(e) : 3; }();
+      // the block behind a downsample conv (its identity still needs that conv's BatchNorm): the kernel's IDBN form.  ST_C3C1_IDBN=0: A/B switch
+      static const bool c3c1_idbn = [] { const char* e = getenv("ST_C3C1_IDBN"); return !e || atoi(e) != 0; }();
       bool c3c1 = false;
       if (use_img && (c3c1_env & (c3.cout == 1024 ? 1 : 2)) && bi + 1 < r->blocks.size()) {
         const BlockL& nb = r->blocks[bi + 1];
         const ConvL& n1 = r->convs[nb.c1];
         // the kernel indexes both fragment-major filter copies with fixed tile permutations: conv3 packed with ntw = 2, conv1 with N / 64
         c3c1 = n1.k == 1 && n1.stride == 1 && c3.k == 1 && c3.stride == 1 && c3.cout == n1.cin && st_conv_c3c1_supported(c3.cin, c3.cout, n1.cout) &&
-               c3.ntw == 2 && n1.ntw == n1.cout / 64 && (!train || (fuse2_ && b.ds < 0)) && (long)B * h2 * w2 * c3.cout * 2 < (1L << 31);
+               c3.ntw == 2 && n1.ntw == n1.cout / 64 && (!train || (fuse2_ && (b.ds < 0 || c3c1_idbn))) && (long)B * h2 * w2 * c3.cout * 2 < (1L << 31);
       }
       if (c3c1) { defer = true; b2b = true; }
       else if (train && use_img && kfuse_env && bi + 1 < r->blocks.size()) {

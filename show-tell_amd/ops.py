@@ -362,7 +362,7 @@ def conv_b2b(raw2, w3_frag, identity, w1_frag, N, bn2, bn3, count, id_bn=None, e
 
 
 def conv_c3c1(x2, w3_frag, identity, w1_frag, bn2=None, bn3=None, count=None, eps=1e-5, stats=None, stats_replicas=0,
-              scale3=None, shift3=None, scale1=None, shift1=None, relu1=True, x_out=None, out=None):
+              scale3=None, shift3=None, scale1=None, shift1=None, relu1=True, x_out=None, out=None, id_bn=None):
     """st_conv_c3c1: x = relu(bn3(conv3(a2)) + identity) (-> x_out), y = conv1_next(x) for the 14 x 14 Bottlenecks (256 -> 1024 -> 256)
     and the 28 x 28 ones (128 -> 512 -> 128).
     train: bn3 = dict(stats, gamma, beta[, replicas]) (+ bn2 for a raw x2), count; eval: scale3 / shift3 / scale1 / shift1.  Returns (x_out, y)."""
@@ -376,7 +376,7 @@ def conv_c3c1(x2, w3_frag, identity, w1_frag, bn2=None, bn3=None, count=None, ep
     d = ConvC3c1Desc()
     d.x2, d.w3_frag, d.identity, d.x_out, d.w1_frag, d.y = x2.data_ptr(), w3_frag.data_ptr(), identity.data_ptr(), x_out.data_ptr(), w1_frag.data_ptr(), out.data_ptr()
     d.stats, d.stats_replicas = (stats.data_ptr() if stats is not None else None), int(stats_replicas)
-    for nm, bn in (("bn2", bn2), ("bn3", bn3)):
+    for nm, bn in (("bn2", bn2), ("bn3", bn3), ("id", id_bn)):
         if bn is not None:
             _dev(bn["stats"], bn["gamma"], bn["beta"])
             setattr(d, nm + "_stats", bn["stats"].data_ptr()); setattr(d, nm + "_gamma", bn["gamma"].data_ptr()); setattr(d, nm + "_beta", bn["beta"].data_ptr())

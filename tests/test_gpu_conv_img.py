@@ -530,6 +530,19 @@ def test_conv_c3c1_train_equals_astat_bn_act_kstream_bit_for_bit(shape, geo):
         assert (x.float().cpu().permute(0, 3, 1, 2) - xf).abs().max().item() <= 2e-2 * xf.abs().max().item()
     yf = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w1)
     assert (y.float().cpu().permute(0, 3, 1, 2) - yf).abs().max().item() <= 1.5e-2 * yf.abs().max().item()
+    # the block behind a downsample conv: the identity is RAW with its own batch statistics (st_bn_act's res_bn form), bit for bit
+    if n >= 2:
+        idr = (torch.randn(B, H, W, C2, generator=g) * 0.7 + 0.1).bfloat16().cuda()
+        idf = idr.float().reshape(-1, C2)
+        std_ = torch.zeros(2, 2 * C2, device="cuda"); std_[1] = torch.cat([idf.sum(0), (idf * idf).sum(0)])
+        gamd, betd = (torch.rand(C2, generator=g) + 0.5).cuda(), (torch.randn(C2, generator=g) * 0.3).cuda()
+        x_ref2 = ops.bn_act(raw3, gam3, bet3, stats=s3, stats_replicas=4, count=n, relu=True, res=idr,
+                            res_bn=dict(stats=std_, gamma=gamd, beta=betd, stats_replicas=2))
+        y_ref2 = conv1(x_ref2, w1k, C1, stats=torch.zeros(2, 2 * C1, device="cuda"), stats_replicas=2)
+        x_i, y_i = ops.conv_c3c1(x2, w3a, idr, w1k, bn2=bn2, bn3=dict(stats=s3, gamma=gam3, beta=bet3, replicas=4), count=n,
+                                 stats=torch.zeros(2, 2 * C1, device="cuda"), stats_replicas=2, id_bn=dict(stats=std_, gamma=gamd, beta=betd, replicas=2))
+        torch.cuda.synchronize()
+        assert torch.equal(x_i, x_ref2) and torch.equal(y_i, y_ref2)
     # x2 already normalised (bn2 = None): the loader copies it
     a2d = ops.bn_act(x2, gam2, bet2, stats=st2, stats_replicas=3, count=n, relu=True)
     x_b, y_b = ops.conv_c3c1(a2d, w3a, ident, w1k, bn3=dict(stats=s3, gamma=gam3, beta=bet3, replicas=4), count=n, stats=torch.zeros(1, 2 * C1, device="cuda"), stats_replicas=1)
